@@ -1,0 +1,110 @@
+// capi.cpp — the C-ABI entry points of libaprilsam_amd.so (include/aprilsam_amd.h PART 2 and 4).
+// Same names, argument meaning and error behaviour as the reference functions they replace; each one
+// forwards to the HIP runtime in solver.hip.cpp.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/aprilsam_amd.h"
+#include "plan.h"
+#include "solver.h"
+
+extern "C" {
+
+// replaces aprilsam.c:45-64
+void april_graph_cholesky_param_init(april_graph_cholesky_param_t *param) {
+    asam::drop_context(param);                 // a re-initialised param starts with no solver state
+    memset(param, 0, sizeof(*param));
+    param->tikhanov = 0.0001;
+    param->nreordering = 1;
+}
+
+// replaces aprilsam.c:66-85 — frees the owned arrays and param itself (the caller heap-allocates it)
+void april_graph_cholesky_param_destory(april_graph_cholesky_param_t *param) {
+    if (!param) return;
+    asam::drop_context(param);
+    free(param->delta_x); free(param->B); free(param->y); free(param->ordering);
+    // chol / A / tr are never set by this library (reference-owned CPU state)
+    free(param);
+}
+
+// replaces aprilsam.c:87-375
+void april_graph_cholesky(april_graph_t *graph, april_graph_cholesky_param_t *param) { asam::batch_step(graph, param); }
+
+// replaces aprilsam.c:377-576
+void april_graph_cholesky_inc(april_graph_t *graph, april_graph_cholesky_param_t *param) { asam::inc_step(graph, param); }
+
+// replaces aprilsam.c:578-597
+void april_graph_cholesky_inc_solver(april_graph_t *graph, april_graph_cholesky_param_t *param, int *idxs) {
+    (void)idxs;                                // the unknown numbering lives in the side context
+    asam::inc_solve_only(graph, param);
+}
+
+// replaces april_graph.c:79-98
+double april_graph_chi2(april_graph_t *graph) { return asam::graph_chi2(graph); }
+
+int aprilsam_amd_device_count(void) { return asam::api_device_count(); }
+int aprilsam_amd_set_device(int device) { return asam::api_set_device(device); }
+int aprilsam_amd_set_option(const char *name, double value) { return asam::api_set_option(name, value); }
+int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_amd_stats_t *out) {
+    return asam::get_stats(param, out) ? 0 : -1;
+}
+int aprilsam_amd_batch_resident(april_graph_t *graph, april_graph_cholesky_param_t *param, int iters, double *chi2_out, double *ms_out) {
+    return asam::batch_resident(graph, param, iters, chi2_out, ms_out);
+}
+const char *aprilsam_amd_version(void) { return "aprilsam_amd 0.1 (gfx950, multifrontal FP64)"; }
+void aprilsam_amd_free(void *p) { free(p); }
+
+// ---- host-logic introspection: ordering + symbolic plan, no GPU involved -------------------------------
+struct aprilsam_amd_plan { asam::Plan P; };
+
+aprilsam_amd_plan_t *aprilsam_amd_plan_create(int n_nodes, int n_factors, const int *factor_nodes, const double *xy, int leaf_nodes) {
+    aprilsam_amd_plan *pl = new aprilsam_amd_plan();
+    asam::build_plan(pl->P, n_nodes, n_factors, factor_nodes, xy, leaf_nodes > 0 ? leaf_nodes : asam::g_opt.leaf_nodes);
+    return pl;
+}
+void aprilsam_amd_plan_destroy(aprilsam_amd_plan_t *plan) { delete plan; }
+
+long long aprilsam_amd_plan_query(const aprilsam_amd_plan_t *plan, const char *what, long long **out) {
+    const asam::Plan &P = plan->P;
+    std::vector<long long> v;
+    auto from = [&](const auto &a) { v.assign(a.begin(), a.end()); };
+    std::string k(what);
+    if (k == "perm") from(P.perm);
+    else if (k == "pos") from(P.pos);
+    else if (k == "front_first") from(P.f_first);
+    else if (k == "front_nsb") from(P.f_nsb);
+    else if (k == "front_nub") from(P.f_nub);
+    else if (k == "front_parent") from(P.f_parent);
+    else if (k == "front_level") from(P.f_level);
+    else if (k == "front_rows_ptr") from(P.f_rows_ptr);
+    else if (k == "front_rows") from(P.f_rows);
+    else if (k == "front_rel") from(P.f_rel);
+    else if (k == "front_off") from(P.f_off);
+    else if (k == "ch_ptr") from(P.ch_ptr);
+    else if (k == "ch_idx") from(P.ch_idx);
+    else if (k == "factor_front") from(P.fac_front);
+    else if (k == "factor_la") from(P.fac_la);
+    else if (k == "factor_lb") from(P.fac_lb);
+    else if (k == "factor_swap") from(P.fac_swap);
+    else if (k == "bd_front_ptr") from(P.bd_front_ptr);
+    else if (k == "bd_row") from(P.bd_row);
+    else if (k == "bd_col") from(P.bd_col);
+    else if (k == "bd_src_ptr") from(P.bd_src_ptr);
+    else if (k == "bd_src") from(P.bd_src);
+    else if (k == "rd_front_ptr") from(P.rd_front_ptr);
+    else if (k == "rd_col") from(P.rd_col);
+    else if (k == "rd_src_ptr") from(P.rd_src_ptr);
+    else if (k == "rd_src") from(P.rd_src);
+    else if (k == "lev_ptr") from(P.lev_ptr);
+    else if (k == "lev_fronts") from(P.lev_fronts);
+    else if (k == "stats") v = { P.nF, P.nLevels, P.max_rows, (long long)P.nnzL, (long long)P.flops, (long long)P.pool_doubles };
+    else { *out = nullptr; return -1; }
+    *out = (long long *)malloc(sizeof(long long) * (v.size() + 1));
+    memcpy(*out, v.data(), sizeof(long long) * v.size());
+    return (long long)v.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// ordering.cpp — nested-dissection ordering of the pose graph (host, C++).
+//
+// Replaces the reference's heap_minimum_degree_ordering (aprilsam.c:999-1249).  That routine need not
+// be reproduced: solver results are ordering independent to ~1e-10.  What the GPU
+// needs instead is a SHALLOW, BUSHY elimination tree (few dependent levels => few dependent kernel
+// launches) whose nodes are dense blocks: exactly what nested dissection delivers.
+//
+// Algorithm per connected region: two candidate bisections — (A) median split along the principal axis
+// of the pose positions (pose graphs are spatial: loop closures join nearby poses), (B) a BFS level
+// structure from a pseudo-peripheral vertex — each turned from an edge cut into a MINIMUM vertex
+// separator through Koenig's theorem (Hopcroft-Karp matching on the cut's bipartite graph); the better
+// one wins.  Regions of <= leaf_nodes poses become dense leaves.
+#include "plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+
+namespace asam {
+namespace {
+
+struct HopcroftKarp {
+    int nl = 0, nr = 0;
+    std::vector<int> ptr, idx;        // left -> right adjacency
+    std::vector<int> ml, mr, dist, it;
+
+    bool bfs() {
+        std::vector<int> q; q.reserve(nl);
+        bool found = false;
+        for (int u = 0; u < nl; u++) { if (ml[u] < 0) { dist[u] = 0; q.push_back(u); } else dist[u] = -1; }
+        for (size_t h = 0; h < q.size(); h++) {
+            int u = q[h];
+            for (int e = ptr[u]; e < ptr[u + 1]; e++) {
+                int w = mr[idx[e]];
+                if (w < 0) found = true;
+                else if (dist[w] < 0) { dist[w] = dist[u] + 1; q.push_back(w); }
+            }
+        }
+        return found;
+    }
+    bool dfs(int u) {
+        for (int &e = it[u]; e < ptr[u + 1]; e++) {
+            int v = idx[e], w = mr[v];
+            if (w < 0 || (dist[w] == dist[u] + 1 && dfs(w))) { ml[u] = v; mr[v] = u; return true; }
+        }
+        dist[u] = -1;
+        return false;
+    }
+    void run() {
+        ml.assign(nl, -1); mr.assign(nr, -1); dist.assign(nl, -1); it.assign(nl, 0);
+        while (bfs()) {
+            for (int u = 0; u < nl; u++) it[u] = ptr[u];
+            for (int u = 0; u < nl; u++) if (ml[u] < 0) dfs(u);
+        }
+    }
+    // minimum vertex cover (Koenig): inL[u] / inR[v] = 1 if in cover
+    void cover(std::vector<char> &inL, std::vector<char> &inR) {
+        std::vector<char> zl(nl, 0), zr(nr, 0);
+        std::vector<int> q;
+        for (int u = 0; u < nl; u++) if (ml[u] < 0) { zl[u] = 1; q.push_back(u); }
+        for (size_t h = 0; h < q.size(); h++) {
+            int u = q[h];
+            for (int e = ptr[u]; e < ptr[u + 1]; e++) {
+                int v = idx[e];
+                if (ml[u] == v || zr[v]) continue;      // follow NON-matching edges left->right
+                zr[v] = 1;
+                int w = mr[v];                          // matching edge right->left
+                if (w >= 0 && !zl[w]) { zl[w] = 1; q.push_back(w); }
+            }
+        }
+        inL.assign(nl, 0); inR.assign(nr, 0);
+        for (int u = 0; u < nl; u++) inL[u] = !zl[u];
+        for (int v = 0; v < nr; v++) inR[v] = zr[v];
+    }
+};
+
+struct Dissector {
+    int N;
+    const std::vector<int> &ap, &ai;
+    const double *xy;
+    int leaf;
+    NDTree &tree;
+    std::vector<int> label;     // region label of each vertex, -1 once placed in a tree node
+    int next_label = 0;
+    std::vector<int> dist, loc; // scratch (size N)
+    std::vector<char> side;     // scratch (size N)
+
+    Dissector(int N_, const std::vector<int> &ap_, const std::vector<int> &ai_, const double *xy_, int leaf_, NDTree &t)
+        : N(N_), ap(ap_), ai(ai_), xy(xy_), leaf(leaf_), tree(t), label(N_, 0), dist(N_, -1), loc(N_, -1), side(N_, 0) {}
+
+    int new_node(std::vector<int> &&verts, int parent) {
+        int id = (int)tree.nodes.size();
+        tree.nodes.emplace_back();
+        tree.nodes.back().verts = std::move(verts);
+        if (parent < 0) tree.roots.push_back(id); else tree.nodes[parent].children.push_back(id);
+        return id;
+    }
+
+    // BFS inside region L from s; returns visit order; dist[] filled for visited vertices.
+    void bfs(int s, int L, std::vector<int> &order) {
+        order.clear(); order.push_back(s); dist[s] = 0;
+        for (size_t h = 0; h < order.size(); h++) {
+            int u = order[h];
+            for (int e = ap[u]; e < ap[u + 1]; e++) {
+                int v = ai[e];
+                if (label[v] == L && dist[v] < 0) { dist[v] = dist[u] + 1; order.push_back(v); }
+            }
+        }
+    }
+
+    struct Split { std::vector<int> S, P0, P1; double cost = 1e300; bool ok = false; };
+
+    // side[v] in {0,1} given for all v of comp: edge cut -> minimum vertex separator
+    void cut_to_separator(const std::vector<int> &comp, int L, Split &out) {
+        std::vector<int> B0, B1;
+        for (int v : comp) {
+            bool b = false;
+            for (int e = ap[v]; e < ap[v + 1] && !b; e++) { int w = ai[e]; b = (label[w] == L && side[w] != side[v]); }
+            if (b) { if (side[v] == 0) { loc[v] = (int)B0.size(); B0.push_back(v); } else { loc[v] = (int)B1.size(); B1.push_back(v); } }
+        }
+        if (B0.empty() || B1.empty()) { out.ok = false; return; }
+        HopcroftKarp hk; hk.nl = (int)B0.size(); hk.nr = (int)B1.size();
+        hk.ptr.assign(hk.nl + 1, 0);
+        for (int i = 0; i < hk.nl; i++) {
+            int v = B0[i];
+            for (int e = ap[v]; e < ap[v + 1]; e++) { int w = ai[e]; if (label[w] == L && side[w] == 1) hk.idx.push_back(loc[w]); }
+            hk.ptr[i + 1] = (int)hk.idx.size();
+        }
+        hk.run();
+        std::vector<char> inL, inR; hk.cover(inL, inR);
+        // mark separator members with loc = -2 (loc is reset to -1 below)
+        for (int i = 0; i < hk.nl; i++) loc[B0[i]] = inL[i] ? -2 : -1;
+        for (int i = 0; i < hk.nr; i++) loc[B1[i]] = inR[i] ? -2 : -1;
+        out.S.clear(); out.P0.clear(); out.P1.clear();
+        for (int v : comp) {
+            if (loc[v] == -2) { out.S.push_back(v); loc[v] = -1; }
+            else if (side[v] == 0) out.P0.push_back(v); else out.P1.push_back(v);
+        }
+        out.ok = !out.P0.empty() && !out.P1.empty() && !out.S.empty();
+        if (out.ok) {
+            double n = (double)comp.size() - (double)out.S.size();
+            double imb = std::max(out.P0.size(), out.P1.size()) / n;       // 0.5 .. 1
+            out.cost = (double)out.S.size() * (1.0 + 4.0 * std::max(0.0, imb - 0.6));
+        }
+    }
+
+    void split_bfs(const std::vector<int> &comp, int L, Split &out) {
+        std::vector<int> order;
+        int s = comp[0];
+        for (int sweep = 0; sweep < 2; sweep++) {           // pseudo-peripheral start
+            bfs(s, L, order);
+            s = order.back();
+            for (int v : order) dist[v] = -1;
+        }
+        bfs(s, L, order);
+        int maxd = dist[order.back()];
+        if (maxd < 2) { for (int v : order) dist[v] = -1; out.ok = false; return; }
+        // order is sorted by dist: choose the level boundary nearest to half
+        size_t half = comp.size() / 2;
+        int c = dist[order[half]];
+        // candidates c and c+1: number of vertices with dist < c
+        auto count_lt = [&](int cc) { size_t lo = 0, hi = order.size(); while (lo < hi) { size_t m = (lo + hi) / 2; if (dist[order[m]] < cc) lo = m + 1; else hi = m; } return lo; };
+        size_t n0 = count_lt(c), n1 = count_lt(c + 1);
+        if (c < 1 || (c + 1 <= maxd && (half - n0) > (n1 - half))) c = c + 1;
+        if (c < 1) c = 1;
+        if (c > maxd) c = maxd;
+        for (int v : comp) side[v] = dist[v] < c ? 0 : 1;
+        for (int v : order) dist[v] = -1;
+        cut_to_separator(comp, L, out);
+    }
+
+    void split_geometric(const std::vector<int> &comp, int L, Split &out) {
+        if (!xy) { out.ok = false; return; }
+        double mx = 0, my = 0; size_t n = comp.size();
+        for (int v : comp) { mx += xy[2 * v]; my += xy[2 * v + 1]; }
+        mx /= n; my /= n;
+        double sxx = 0, sxy = 0, syy = 0;
+        for (int v : comp) { double dx = xy[2 * v] - mx, dy = xy[2 * v + 1] - my; sxx += dx * dx; sxy += dx * dy; syy += dy * dy; }
+        if (!(std::isfinite(sxx) && std::isfinite(syy) && std::isfinite(sxy))) { out.ok = false; return; }
+        // principal direction of the 2x2 covariance
+        double th = 0.5 * std::atan2(2 * sxy, sxx - syy);
+        double ux = std::cos(th), uy = std::sin(th);
+        std::vector<std::pair<double, int>> pr(n);
+        for (size_t i = 0; i < n; i++) { int v = comp[i]; pr[i] = { (xy[2 * v] - mx) * ux + (xy[2 * v + 1] - my) * uy, v }; }
+        std::nth_element(pr.begin(), pr.begin() + n / 2, pr.end());
+        for (size_t i = 0; i < n; i++) side[pr[i].second] = i < n / 2 ? 0 : 1;
+        cut_to_separator(comp, L, out);
+    }
+
+    void run() {
+        struct Item { std::vector<int> verts; int parent; };
+        std::vector<Item> stack;
+        { Item it; it.verts.resize(N); std::iota(it.verts.begin(), it.verts.end(), 0); it.parent = -1; stack.push_back(std::move(it)); }
+        std::vector<int> order;
+        while (!stack.empty()) {
+            Item item = std::move(stack.back()); stack.pop_back();
+            int L = ++next_label;
+            for (int v : item.verts) label[v] = L;
+            // connected components of the region
+            for (int s : item.verts) {
+                if (label[s] != L) continue;
+                bfs(s, L, order);
+                std::vector<int> comp(order);
+                for (int v : comp) dist[v] = -1;
+                int Lc = ++next_label;
+                for (int v : comp) label[v] = Lc;
+                std::sort(comp.begin(), comp.end());
+                handle(comp, Lc, item.parent, stack);
+            }
+        }
+    }
+
+    template <class Stack>
+    void handle(std::vector<int> &comp, int L, int parent, Stack &stack) {
+        if ((int)comp.size() <= leaf) { for (int v : comp) label[v] = -1; new_node(std::move(comp), parent); return; }
+        Split a, b;
+        split_geometric(comp, L, a);
+        split_bfs(comp, L, b);
+        Split *best = nullptr;
+        if (a.ok) best = &a;
+        if (b.ok && (!best || b.cost < best->cost)) best = &b;
+        if (!best) { for (int v : comp) label[v] = -1; new_node(std::move(comp), parent); return; }   // dense region
+        for (int v : best->S) label[v] = -1;
+        int t = new_node(std::move(best->S), parent);
+        stack.push_back({ std::move(best->P0), t });
+        stack.push_back({ std::move(best->P1), t });
+    }
+};
+
+}  // namespace
+
+void nested_dissection(int N, const std::vector<int> &adj_ptr, const std::vector<int> &adj,
+                       const double *xy, int leaf_nodes, NDTree &tree) {
+    tree.nodes.clear(); tree.roots.clear();
+    if (N <= 0) return;
+    if (leaf_nodes < 1) leaf_nodes = 1;
+    Dissector d(N, adj_ptr, adj, xy, leaf_nodes, tree);
+    d.run();
+}
+
+}  // namespace asam

@@ -1,0 +1,29 @@
+// solver.h — internal interface between the C-ABI layer (capi.cpp) and the HIP runtime (solver.hip.cpp)
+#pragma once
+#include "../../include/aprilsam_amd.h"
+
+namespace asam {
+
+struct Options {
+    int leaf_nodes = 16;          // nested-dissection leaf size (pose nodes)
+    int deterministic = 1;        // 1: the wall-clock fallback rule aprilsam.c:557 is disabled
+    int use_graph = 1;            // replay the numeric phase from a captured hipGraph
+    int device_timing = 0;        // record HIP events per stage (disables graph replay for that call)
+    int trust_factor_cache = 1;   // z/W of factors already packed are treated as immutable
+    int small_lds_kb = 100;       // fronts whose LDS image fits run in the single-workgroup LDS kernel
+};
+extern Options g_opt;
+
+void batch_step(april_graph_t *g, april_graph_cholesky_param_t *param);
+void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param);
+void inc_solve_only(april_graph_t *g, april_graph_cholesky_param_t *param);
+double graph_chi2(april_graph_t *g);
+int batch_resident(april_graph_t *g, april_graph_cholesky_param_t *param, int iters, double *chi2_out, double *ms_out);
+void drop_context(const april_graph_cholesky_param_t *p);
+void drop_graph_pack(const april_graph_t *g);
+bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out);
+int api_device_count();
+int api_set_device(int d);
+int api_set_option(const char *name, double v);
+
+}  // namespace asam

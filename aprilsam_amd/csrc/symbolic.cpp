@@ -1,0 +1,182 @@
+// symbolic.cpp — supernodal symbolic analysis on the pose-block graph (host, C++).
+//
+// Counterpart of the reference's symbolic stages: cs_schol (csparse.c:1693: etree, postorder, column
+// counts), search_tree_create_from_smat (aprilsam.c:613-657: block elimination tree) and the idxs
+// numbering (aprilsam.c:141-148) — restructured for a multifrontal GPU factorisation: every nested-
+// dissection tree node is ONE dense front; we compute each front's update-row structure, the assembly
+// tree, child->parent scatter maps, the factor->front assignment with deterministic gather lists, and a
+// level schedule (fronts of one level are independent => one batched kernel launch).
+#include "plan.h"
+
+#include <algorithm>
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+#include <tuple>
+
+namespace asam {
+
+void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf_nodes) {
+    P = Plan();
+    P.N = N; P.F = F; P.leaf_nodes = leaf_nodes;
+    if (N <= 0) return;
+
+    // ---- pose adjacency (deduplicated CSR) ------------------------------------------------------------
+    std::vector<int> ap(N + 1, 0), ai;
+    {
+        std::vector<int> deg(N, 0);
+        for (int f = 0; f < F; f++) { int a = fn[2 * f], b = fn[2 * f + 1]; if (b >= 0 && a != b) { deg[a]++; deg[b]++; } }
+        for (int i = 0; i < N; i++) ap[i + 1] = ap[i] + deg[i];
+        ai.resize(ap[N]);
+        std::vector<int> fill(ap.begin(), ap.end() - 1);
+        for (int f = 0; f < F; f++) { int a = fn[2 * f], b = fn[2 * f + 1]; if (b >= 0 && a != b) { ai[fill[a]++] = b; ai[fill[b]++] = a; } }
+        // sort + unique per row, then compact
+        std::vector<int> np(N + 1, 0); int w = 0;
+        for (int i = 0; i < N; i++) {
+            std::sort(ai.begin() + ap[i], ai.begin() + ap[i + 1]);
+            int last = -1;
+            for (int e = ap[i]; e < ap[i + 1]; e++) if (ai[e] != last) { last = ai[e]; ai[w++] = last; }
+            np[i + 1] = w;
+        }
+        ai.resize(w); ap.swap(np);
+    }
+
+    // ---- nested dissection tree, post-order numbering ----------------------------------------------
+    NDTree tree;
+    nested_dissection(N, ap, ai, xy, leaf_nodes, tree);
+    const int nT = (int)tree.nodes.size();
+    P.nF = nT;
+    P.perm.assign(N, -1); P.pos.assign(N, -1);
+    P.f_first.assign(nT, 0); P.f_nsb.assign(nT, 0);
+    std::vector<int> tfront(nT, -1);        // ND tree node -> front index (post-order)
+    {
+        int nextpos = 0, nextfront = 0;
+        std::vector<std::pair<int, size_t>> st;     // (tree node, next child)
+        for (int r : tree.roots) {
+            st.push_back({ r, 0 });
+            while (!st.empty()) {
+                auto &top = st.back();
+                NDTree::Node &nd = tree.nodes[top.first];
+                if (top.second < nd.children.size()) { int c = nd.children[top.second++]; st.push_back({ c, 0 }); continue; }
+                int t = nextfront++;
+                tfront[top.first] = t;
+                P.f_first[t] = nextpos; P.f_nsb[t] = (int)nd.verts.size();
+                for (int v : nd.verts) { P.perm[nextpos] = v; P.pos[v] = nextpos; nextpos++; }
+                st.pop_back();
+            }
+        }
+        assert(nextpos == N && nextfront == nT);
+    }
+    std::vector<int> pos_front(N);
+    for (int t = 0; t < nT; t++) for (int k = 0; k < P.f_nsb[t]; k++) pos_front[P.f_first[t] + k] = t;
+
+    // ---- structure of every front (block positions > own range), assembly tree -----------------------
+    P.f_nub.assign(nT, 0); P.f_parent.assign(nT, -1); P.f_rows_ptr.assign(nT + 1, 0);
+    std::vector<std::vector<int>> kids(nT);
+    std::vector<int> mark(N, -1), tmp;
+    std::vector<std::vector<int>> strct(nT);
+    for (int t = 0; t < nT; t++) {
+        const int last = P.f_first[t] + P.f_nsb[t] - 1;
+        tmp.clear();
+        for (int p = P.f_first[t]; p <= last; p++) {
+            int v = P.perm[p];
+            for (int e = ap[v]; e < ap[v + 1]; e++) { int q = P.pos[ai[e]]; if (q > last && mark[q] != t) { mark[q] = t; tmp.push_back(q); } }
+        }
+        for (int c : kids[t]) for (int q : strct[c]) if (q > last && mark[q] != t) { mark[q] = t; tmp.push_back(q); }
+        std::sort(tmp.begin(), tmp.end());
+        strct[t] = tmp;
+        P.f_nub[t] = (int)tmp.size();
+        if (!tmp.empty()) { int par = pos_front[tmp[0]]; assert(par > t); P.f_parent[t] = par; kids[par].push_back(t); }
+    }
+    for (int t = 0; t < nT; t++) P.f_rows_ptr[t + 1] = P.f_rows_ptr[t] + P.f_nub[t];
+    P.f_rows.resize(P.f_rows_ptr[nT]); P.f_rel.assign(P.f_rows_ptr[nT], -1);
+    for (int t = 0; t < nT; t++) std::copy(strct[t].begin(), strct[t].end(), P.f_rows.begin() + P.f_rows_ptr[t]);
+
+    auto local_index = [&](int t, int p) -> int {      // block index of position p inside front t (or -1)
+        if (p >= P.f_first[t] && p < P.f_first[t] + P.f_nsb[t]) return p - P.f_first[t];
+        const int *b = P.f_rows.data() + P.f_rows_ptr[t], *e = b + P.f_nub[t];
+        const int *it = std::lower_bound(b, e, p);
+        if (it == e || *it != p) return -1;
+        return P.f_nsb[t] + (int)(it - b);
+    };
+    for (int t = 0; t < nT; t++) {
+        int par = P.f_parent[t];
+        for (int64_t k = P.f_rows_ptr[t]; k < P.f_rows_ptr[t + 1]; k++) {
+            int li = local_index(par, P.f_rows[k]);
+            if (li < 0) { fprintf(stderr, "aprilsam_amd: symbolic inconsistency (front %d row %d)\n", t, P.f_rows[k]); abort(); }
+            P.f_rel[k] = li;
+        }
+    }
+    P.ch_ptr.assign(nT + 1, 0);
+    for (int t = 0; t < nT; t++) P.ch_ptr[t + 1] = P.ch_ptr[t] + (int)kids[t].size();
+    P.ch_idx.resize(P.ch_ptr[nT]);
+    for (int t = 0; t < nT; t++) std::copy(kids[t].begin(), kids[t].end(), P.ch_idx.begin() + P.ch_ptr[t]);
+
+    // ---- levels ------------------------------------------------------------------------------------------
+    P.f_level.assign(nT, 0);
+    for (int t = 0; t < nT; t++) { int par = P.f_parent[t]; if (par >= 0) P.f_level[par] = std::max(P.f_level[par], P.f_level[t] + 1); }
+    P.nLevels = 0;
+    for (int t = 0; t < nT; t++) P.nLevels = std::max(P.nLevels, P.f_level[t] + 1);
+    P.lev_ptr.assign(P.nLevels + 1, 0);
+    for (int t = 0; t < nT; t++) P.lev_ptr[P.f_level[t] + 1]++;
+    for (int l = 0; l < P.nLevels; l++) P.lev_ptr[l + 1] += P.lev_ptr[l];
+    P.lev_fronts.resize(nT);
+    { std::vector<int> fill(P.lev_ptr.begin(), P.lev_ptr.end() - 1); for (int t = 0; t < nT; t++) P.lev_fronts[fill[P.f_level[t]]++] = t; }
+
+    // ---- factor -> front assignment + deterministic gather lists -------------------------------------
+    P.fac_front.assign(F, -1); P.fac_la.assign(F, -1); P.fac_lb.assign(F, -1); P.fac_swap.assign(F, 0);
+    struct Dest { int front, col, row, src; };
+    std::vector<Dest> bd, rd; bd.reserve((size_t)3 * F); rd.reserve((size_t)2 * F);
+    for (int f = 0; f < F; f++) {
+        int a = fn[2 * f], b = fn[2 * f + 1];
+        if (a < 0 || a >= N || b >= N || a == b) continue;          // malformed: ignored
+        int pa = P.pos[a], pb = b >= 0 ? P.pos[b] : -1;
+        int t = pos_front[(pb >= 0 && pb < pa) ? pb : pa];
+        int la = local_index(t, pa), lb = pb >= 0 ? local_index(t, pb) : -1;
+        if (la < 0 || (pb >= 0 && lb < 0)) { fprintf(stderr, "aprilsam_amd: factor %d not inside its front\n", f); abort(); }
+        P.fac_front[f] = t; P.fac_la[f] = la; P.fac_lb[f] = lb;
+        bd.push_back({ t, la, la, 3 * f + 0 });
+        rd.push_back({ t, la, 0, 2 * f + 0 });
+        if (lb >= 0) {
+            P.fac_swap[f] = la < lb;
+            bd.push_back({ t, std::min(la, lb), std::max(la, lb), 3 * f + 1 });
+            bd.push_back({ t, lb, lb, 3 * f + 2 });
+            rd.push_back({ t, lb, 0, 2 * f + 1 });
+        }
+    }
+    auto cmp = [](const Dest &x, const Dest &y) { return std::tie(x.front, x.col, x.row, x.src) < std::tie(y.front, y.col, y.row, y.src); };
+    std::sort(bd.begin(), bd.end(), cmp);
+    std::sort(rd.begin(), rd.end(), cmp);
+    auto compress = [&](const std::vector<Dest> &v, std::vector<int> &front_ptr, std::vector<int> &row, std::vector<int> &col,
+                        std::vector<int> &src_ptr, std::vector<int> &src) {
+        front_ptr.assign(nT + 1, 0); row.clear(); col.clear(); src_ptr.clear(); src.clear();
+        src_ptr.push_back(0);
+        for (size_t i = 0; i < v.size(); i++) {
+            bool fresh = i == 0 || v[i].front != v[i - 1].front || v[i].col != v[i - 1].col || v[i].row != v[i - 1].row;
+            if (fresh) { if (i) src_ptr.push_back((int)src.size()); row.push_back(v[i].row); col.push_back(v[i].col); front_ptr[v[i].front + 1]++; }
+            src.push_back(v[i].src);
+        }
+        if (!v.empty()) src_ptr.push_back((int)src.size());
+        for (int t = 0; t < nT; t++) front_ptr[t + 1] += front_ptr[t];
+    };
+    std::vector<int> dummy_row;
+    compress(bd, P.bd_front_ptr, P.bd_row, P.bd_col, P.bd_src_ptr, P.bd_src);
+    compress(rd, P.rd_front_ptr, dummy_row, P.rd_col, P.rd_src_ptr, P.rd_src);
+
+    // ---- HBM pool offsets + statistics -----------------------------------------------------------------
+    P.f_off.assign(nT, 0);
+    int64_t off = 0;
+    P.max_rows = 0; P.nnzL = 0; P.flops = 0;
+    for (int t = 0; t < nT; t++) {
+        P.f_off[t] = off;
+        int64_t sz = (int64_t)P.rows(t) * P.cols(t);
+        off += (sz + 31) & ~int64_t(31);                          // 256-byte aligned fronts
+        int ns = 3 * P.f_nsb[t], nu = 3 * P.f_nub[t];
+        P.max_rows = std::max(P.max_rows, ns + nu);
+        P.nnzL += (int64_t)ns * (ns + 1) / 2 + (int64_t)nu * ns;
+        for (int q = 0; q < ns; q++) { double c = (double)(ns - q) + nu; P.flops += c * c; }
+    }
+    P.pool_doubles = off;
+}
+
+}  // namespace asam

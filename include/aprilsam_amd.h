@@ -1,0 +1,238 @@
+/* aprilsam_amd.h — C-ABI of libaprilsam_amd.so: the MI355X-native replacement for AprilSAM's
+ * Gauss-Newton hot path (april_graph_cholesky / april_graph_cholesky_inc).
+ *
+ * The reference host program keeps compiling against its own aprilsam/aprilsam.h and simply links
+ * (or dlopens) this library instead of libaprilsam.so for the symbols declared in PART 2.  PART 1
+ * restates — from the measured LP64 layout, SURVEY.md §8(b) — the structs that cross the boundary,
+ * so that this library, its tests and its Python mirror agree byte-for-byte with objects created by
+ * reference-compiled code.  Nothing here carries torch or HIP types: plain pointers and sizes only.
+ *
+ * Citations are relative to the reference tree (xipengwang/AprilSAM @ v1).
+ */
+#ifndef APRILSAM_AMD_H
+#define APRILSAM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * PART 1 — boundary structs (layout-compatible restatements)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* common/zarray.h:44-51 — 24 bytes; graph->nodes / graph->factors hold POINTERS as elements. */
+typedef struct zarray {
+    size_t el_sz;
+    int    size;
+    int    alloc;
+    char  *data;
+} zarray_t;
+
+/* common/matd.h:46-51 — row-major dense matrix with a flexible data tail. */
+typedef struct matd {
+    unsigned int nrows, ncols;
+    double       data[];
+} matd_t;
+
+/* aprilsam.h:65-72 — 32 bytes. attr/stype are opaque to the hot path. */
+typedef struct april_graph {
+    zarray_t   *factors;   /* elements: april_graph_factor_t*  */
+    zarray_t   *nodes;     /* elements: april_graph_node_t*    */
+    void       *attr;
+    const void *stype;
+} april_graph_t;
+
+/* aprilsam.h:75-89 — result of a factor->eval() call (only produced by the host-side vtable
+ * entries this library installs on the objects IT creates; the device path never builds one). */
+typedef struct april_graph_factor_eval {
+    double   chi2;
+    matd_t **jacobians;   /* NULL-terminated, one per connected node */
+    int      length;
+    double  *r;
+    matd_t  *W;
+} april_graph_factor_eval_t;
+
+#define APRIL_GRAPH_FACTOR_XYT_TYPE    1     /* aprilsam.h:91 */
+#define APRIL_GRAPH_FACTOR_XYTPOS_TYPE 2     /* aprilsam.h:92 */
+#define APRIL_GRAPH_NODE_XYT_TYPE      100   /* aprilsam.h:94 */
+
+typedef struct april_graph_factor april_graph_factor_t;
+typedef struct april_graph_node   april_graph_node_t;
+
+/* aprilsam.h:98-146 — 104 bytes. The device path recognises type 1 (xyt) and 2 (xytpos) and reads
+ * nodes[], u.common.z and u.common.W directly; function pointers are never called on the device. */
+struct april_graph_factor {
+    int   type;
+    int   nnodes;
+    int  *nodes;
+    int   length;
+    void *attr;
+    april_graph_factor_t      *(*copy)(april_graph_factor_t *factor);
+    april_graph_factor_eval_t *(*eval)(april_graph_factor_t *factor, april_graph_t *graph,
+                                       april_graph_factor_eval_t *eval);
+    april_graph_factor_eval_t *(*state_eval)(april_graph_factor_t *factor, april_graph_t *graph,
+                                             april_graph_factor_eval_t *eval);
+    void (*destroy)(april_graph_factor_t *factor);
+    union {
+        struct { double *z; double *ztruth; matd_t *W; void *impl; } common;
+        struct { april_graph_factor_t **factors; double *logw; int nfactors; } max;
+        struct { void *impl; } impl;
+    } u;
+    const void *stype;
+};
+
+/* aprilsam.h:151-179 — 112 bytes. */
+struct april_graph_node {
+    int     UID;
+    int     type;
+    int     length;
+    double *state;
+    double *init;
+    double *truth;
+    double *l_point;
+    double *delta_X;
+    void   *attr;
+    april_graph_node_t *(*copy)(april_graph_node_t *node);
+    void (*update)(april_graph_node_t *node, double *dstate);
+    void (*relinearize)(april_graph_node_t *node);
+    void (*destroy)(april_graph_node_t *node);
+    void       *impl;
+    const void *stype;
+};
+
+/* aprilsam.h:231-265 — 128 bytes.  chol / A / tr are the reference's CPU solver state; this library
+ * keeps its (device) solver state in a side context keyed by the param pointer and leaves those
+ * three NULL, so a reference-compiled april_graph_cholesky_param_destory() stays safe. `ordering`
+ * is always a malloc() block (or NULL); factor_num / nreordering / batch_time keep their meaning. */
+typedef struct april_graph_cholesky_param {
+    double  tikhanov;      /* lambda added to every diagonal in a batch step (default 1e-4) */
+    void   *chol;          /* unused here (NULL) */
+    int     factor_num;    /* #factors folded into the current factorisation */
+    int    *ordering;      /* position -> node id of the current elimination order */
+    int     nreordering;   /* #nodes in the current factorisation; must be non-zero on entry */
+    int     show_timing;
+    double *delta_x;       /* kept only if pre-allocated by the caller (aprilsam.c:363-366) */
+    double *B;             /* unused here (NULL) */
+    double *y;             /* unused here (NULL) */
+    void   *A;             /* unused here (NULL) */
+    void   *tr;            /* unused here (NULL) */
+    double  l_thresh;
+    double  delta_thresh;
+    int     nthreshold;
+    double  batch_time;
+    double  delta_xy;
+    double  delta_theta;
+} april_graph_cholesky_param_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * PART 2 — the drop-in entry points (same names, arguments and error behaviour as the reference)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* replaces aprilsam.c:45-64 */
+void april_graph_cholesky_param_init(april_graph_cholesky_param_t *param);
+/* replaces aprilsam.c:66-85 (frees the side context, the owned arrays AND param itself) */
+void april_graph_cholesky_param_destory(april_graph_cholesky_param_t *param);
+/* replaces aprilsam.c:87-375 — one batch Gauss-Newton step on the GPU; synchronous: every
+ * node->state / l_point / delta_X is valid in host memory on return. Silent no-op on an empty graph. */
+void april_graph_cholesky(april_graph_t *graph, april_graph_cholesky_param_t *param);
+/* replaces aprilsam.c:377-576 — incremental step (new nodes/factors since the last call). */
+void april_graph_cholesky_inc(april_graph_t *graph, april_graph_cholesky_param_t *param);
+/* replaces aprilsam.c:578-597 — solve + state update of the current incremental factorisation. */
+void april_graph_cholesky_inc_solver(april_graph_t *graph, april_graph_cholesky_param_t *param, int *idxs);
+/* replaces april_graph.c:79-98 — chi^2 with the reference's 1/2-on-xyt-only convention (GPU). */
+double april_graph_chi2(april_graph_t *graph);
+
+/* ------------------------------------------------------------------------------------------------
+ * PART 3 — host-side object constructors with the reference's names and ABI, so a caller (or a
+ * test) can build a graph without the reference library.  replaces april_graph.c:329-364,
+ * april_graph_xyt.c:276-298,420-438, april_graph_xytpos.c:191-211, april_graph.c:33-49.
+ * ---------------------------------------------------------------------------------------------- */
+april_graph_t *april_graph_create(void);
+void           april_graph_destroy(april_graph_t *graph);
+april_graph_node_t   *april_graph_node_xyt_create(const double *state, const double *init, const double *truth);
+april_graph_factor_t *april_graph_factor_xyt_create(int a, int b, const double *z, const double *ztruth, const matd_t *W);
+april_graph_factor_t *april_graph_factor_xytpos_create(int a, double *z, double *ztruth, matd_t *W);
+void april_graph_factor_eval_destroy(april_graph_factor_eval_t *eval);
+int  april_graph_dof(april_graph_t *graph);
+
+/* ------------------------------------------------------------------------------------------------
+ * PART 4 — extensions (prefix aprilsam_amd_). Not part of the reference API.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* zarray_add is `static inline` in the reference (common/zarray.h:180-189), so it is not an
+ * exported symbol there either; these two do the same append for callers without that header. */
+void aprilsam_amd_graph_add_node(april_graph_t *graph, april_graph_node_t *node);
+void aprilsam_amd_graph_add_factor(april_graph_t *graph, april_graph_factor_t *factor);
+
+/* Number of usable HIP devices (0 => every solver entry point fails loudly). */
+int aprilsam_amd_device_count(void);
+/* Select the HIP device used by contexts created afterwards (default: LOCAL_RANK env or 0). */
+int aprilsam_amd_set_device(int device);
+
+/* Per-param solver statistics of the LAST solver call (all times in milliseconds).  */
+typedef struct aprilsam_amd_stats {
+    int    n_nodes, n_factors;
+    int    n_fronts, n_levels;         /* supernodal assembly tree */
+    int    max_front_rows;             /* largest frontal dimension (scalar rows, w/o rhs row) */
+    int    symbolic_reused;            /* 1 if ordering+symbolic came from the cache */
+    int    not_spd;                    /* 1 if a non-positive pivot was met (states left untouched) */
+    int    reserved0;
+    long long nnz_L;                   /* scalar non-zeros of L incl. diagonal (dense-front count) */
+    double flops_factor;               /* sum_j c_j^2 of our own L (SURVEY §8(d) convention) */
+    double bytes_fronts;               /* bytes of all frontal matrices resident in HBM */
+    double ms_pack, ms_symbolic, ms_h2d, ms_device, ms_d2h, ms_unpack, ms_total;
+    double ms_dev_linearize, ms_dev_factor, ms_dev_solve;   /* HIP-event timings inside ms_device */
+    double chi2_before;                /* chi^2 at the linearisation point (from the linearise kernel) */
+} aprilsam_amd_stats_t;
+int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_amd_stats_t *out);
+
+/* Runtime options (also settable by env APRILSAM_AMD_<NAME>): returns 0 on success.
+ *   "leaf_nodes"        nested-dissection leaf size in pose nodes (default 16)
+ *   "deterministic"     1 = disable the wall-clock fallback rule aprilsam.c:557 (default 1)
+ *   "use_graph"         1 = replay the numeric phase from a captured hipGraph (default 1)
+ *   "device_timing"     1 = record per-stage HIP events (default 0)
+ *   "trust_factor_cache" 1 = z/W of already-seen factors are immutable (default 1)
+ *   "small_lds_kb"      fronts whose LDS image fits this many KiB use the single-workgroup kernel (100) */
+int aprilsam_amd_set_option(const char *name, double value);
+
+/* ---- device-resident benchmark/driver API: states stay in HBM between iterations -------------
+ * aprilsam_amd_batch_resident() runs `iters` batch Gauss-Newton iterations back to back without
+ * touching host node objects in between (states/l_points live in HBM), then writes the final states
+ * back into the graph.  chi2_out (may be NULL) receives iters+1 values: chi^2 before the first
+ * iteration and after each one.  ms_out (may be NULL) receives `iters` HIP-event durations of
+ * the device work per iteration.  Returns 0 on success, <0 on failure (no device, not SPD, ...). */
+int aprilsam_amd_batch_resident(april_graph_t *graph, april_graph_cholesky_param_t *param, int iters,
+                                double *chi2_out, double *ms_out);
+
+/* ---- host-logic introspection (no GPU needed): ordering + symbolic analysis of a graph -------- */
+typedef struct aprilsam_amd_plan aprilsam_amd_plan_t;   /* opaque */
+aprilsam_amd_plan_t *aprilsam_amd_plan_create(int n_nodes, int n_factors, const int *factor_nodes /* 2 per factor, -1 for unary */,
+                                              const double *xy /* 2 per node or NULL */, int leaf_nodes);
+void aprilsam_amd_plan_destroy(aprilsam_amd_plan_t *plan);
+/* query: fills *out with a malloc'ed int64 array the caller frees with aprilsam_amd_free(); returns its length.
+ * what: "perm" (position->node), "front_ptr" , "front_nsb", "front_nub", "front_parent", "front_level",
+ *       "front_rows_ptr", "front_rows" (block positions of every front's rows: own then struct),
+ *       "factor_front", "stats" (n_fronts, n_levels, max_rows, nnzL, flops) */
+long long aprilsam_amd_plan_query(const aprilsam_amd_plan_t *plan, const char *what, long long **out);
+void aprilsam_amd_free(void *p);
+
+/* ---- synthetic Manhattan lattice generator ----------------------- */
+/* Appends K*K xyt nodes, the in-bounds 4-direction xyt factors and the node-0 prior to `graph`.
+ * Returns the number of factors added. */
+int aprilsam_amd_make_lattice(april_graph_t *graph, int K);
+/* The same lattice as plain arrays: states[3*K*K], fa/fb[F] (fb = -1 for the prior), z[3F], W[9F] with
+ * F = 2K(K-1) + 2(K-1)^2 + 1 (caller allocates).  Returns F. */
+int aprilsam_amd_lattice_arrays(int K, double *states, int *fa, int *fb, double *z, double *W);
+/* Bulk append N xyt nodes (state = init = truth) and F factors (fb[i] < 0: xytpos prior on fa[i]). */
+void aprilsam_amd_graph_from_arrays(april_graph_t *graph, int N, const double *states, int F, const int *fa,
+                                    const int *fb, const double *z, const double *W);
+
+const char *aprilsam_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APRILSAM_AMD_H */
