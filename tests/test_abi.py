@@ -1,0 +1,110 @@
+"""Boundary checks that need no GPU: struct layout, exported symbols, host-side object constructors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from aprilsam_amd import abi, datasets
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_struct_layout_matches_reference_abi():
+    for name, size in abi.EXPECTED_SIZES.items():
+        assert C.sizeof(getattr(abi, name)) == size, name
+    for name, offs in abi.EXPECTED_OFFSETS.items():
+        cls = getattr(abi, name)
+        for field, off in offs.items():
+            assert getattr(cls, field).offset == off, (name, field)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "aprilsam_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b((?:april_graph|aprilsam_amd)_[a-z0-9_]+)\s*\(", hdr))
+    assert {"april_graph_cholesky", "april_graph_cholesky_inc", "april_graph_cholesky_inc_solver", "april_graph_chi2",
+            "april_graph_cholesky_param_init", "april_graph_cholesky_param_destory"} <= names
+    for n in sorted(names):
+        assert hasattr(lib.dll, n), f"{n} declared in include/aprilsam_amd.h but not exported"
+
+
+def test_param_init_defaults(lib):
+    p = lib.new_param()
+    assert p.c.tikhanov == pytest.approx(1e-4) and p.c.nreordering == 1      # aprilsam.c:50-52
+    assert not p.c.chol and not p.c.A and not p.c.tr and not p.c.ordering
+    p.destroy()
+
+
+def test_host_objects_have_reference_layout_and_working_vtable(lib, oracle):
+    g = lib.new_graph()
+    g.add_node_xyt([1.0, 2.0, 0.5]); g.add_node_xyt([2.0, 2.5, 0.7])
+    g.add_factor_xytpos(0, [0, 0, 0], datasets.PRIOR_W)
+    W = np.array([[4.0, 0.5, 0.1], [0.5, 3.0, 0.2], [0.1, 0.2, 9.0]])
+    g.add_factor_xyt(0, 1, [1.0, 0.3, 0.25], W)
+    assert g.n_nodes == 2 and g.n_factors == 2
+    n0 = g.node(0)
+    assert n0.type == 100 and n0.length == 3 and [n0.l_point[k] for k in range(3)] == [1.0, 2.0, 0.5]
+    f1 = g.factor(1)
+    assert f1.type == 1 and f1.nnodes == 2 and (f1.nodes[0], f1.nodes[1]) == (0, 1)
+    assert [f1.u.W.contents.data[k] for k in range(9)] == W.reshape(9).tolist()
+    # call the installed eval() through its pointer like reference-compiled code would
+    class Eval(C.Structure):
+        _fields_ = [("chi2", C.c_double), ("jacobians", C.POINTER(C.POINTER(abi.Matd3x3))), ("length", C.c_int),
+                    ("r", C.POINTER(C.c_double)), ("W", C.POINTER(abi.Matd3x3))]
+    proto = C.CFUNCTYPE(C.POINTER(Eval), C.POINTER(abi.Factor), C.POINTER(abi.Graph), C.c_void_p)
+    for fi in (0, 1):
+        fac = g.factor(fi)
+        e = proto(fac.eval)(C.pointer(fac), g.ptr, None).contents
+        st = g.states()
+        J0, J1, r, c = oracle.factor_eval(st[0], st[1] if fi else None, [fac.u.z[k] for k in range(3)],
+                                          [fac.u.W.contents.data[k] for k in range(9)])
+        assert e.chi2 == c and [e.r[k] for k in range(3)] == r.tolist()
+        assert [e.jacobians[0].contents.data[k] for k in range(9)] == J0.tolist()
+        assert bool(e.jacobians[2 if fi else 1]) is False              # NULL-terminated
+        lib.dll.april_graph_factor_eval_destroy(C.byref(e))
+    upd = C.CFUNCTYPE(None, C.POINTER(abi.Node), C.POINTER(C.c_double))(n0.update)
+    upd(C.pointer(n0), (C.c_double * 3)(0.5, -1.0, 3.0))
+    assert [n0.state[k] for k in range(3)] == [1.5, 1.0, oracle.mod2pi(3.5)]
+    assert [n0.delta_X[k] for k in range(3)] == [0.5, -1.0, 3.0]
+    upd(C.pointer(n0), (C.c_double * 3)(float("nan"), 0.0, 0.0))       # NaN guard: untouched
+    assert [n0.state[k] for k in range(2)] == [1.5, 1.0]
+    g.destroy()
+
+
+def test_reference_objects_readable_through_our_abi(reflib):
+    """objects created by the real reference library, read through abi.py (drop-in direction)"""
+    g = reflib.new_graph()
+    g.build_from_arrays(*datasets.random_pose_graph(6, 2, 4))
+    assert g.n_nodes == 6
+    for i in range(g.n_factors):
+        f = g.factor(i)
+        assert f.type in (1, 2) and f.length == 3 and f.u.W.contents.nrows == 3
+    assert g.node(3).type == 100
+    g.destroy()
+
+
+def test_lattice_generator_counts_and_determinism(lib):
+    st, fa, fb, z, W = lib.lattice_arrays(316)
+    assert len(st) == 99856 and len(fa) == 397531
+    assert fb[-1] == -1 and np.all(fb[:-1] > fa[:-1]) and np.all(st[0] == 0)
+    st2 = lib.lattice_arrays(316)[0]
+    assert np.array_equal(st, st2)
+    K = 1000
+    assert 2 * K * (K - 1) + 2 * (K - 1) ** 2 + 1 == 3994003               # config 5
+
+
+def test_solver_entry_points_fail_loudly_without_gpu(lib):
+    """No CPU fallback: on a box without a HIP device the solver aborts with a message (checked in a
+    subprocess so the abort does not take pytest down)."""
+    if lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from aprilsam_amd import host, datasets\n"
+            "l = host.SolverLib(); g = l.new_graph(); g.build_from_arrays(*datasets.random_pose_graph(5, 2, 0))\n"
+            "p = l.new_param(); g.cholesky(p); print('RETURNED')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "RETURNED" not in r.stdout
+    assert "no HIP device" in r.stderr
