@@ -54,6 +54,14 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
 int aprilsam_amd_batch_resident(april_graph_t *graph, april_graph_cholesky_param_t *param, int iters, double *chi2_out, double *ms_out) {
     return asam::batch_resident(graph, param, iters, chi2_out, ms_out);
 }
+int aprilsam_amd_resident_begin(april_graph_t *graph, april_graph_cholesky_param_t *param) { return asam::resident_begin(graph, param); }
+int aprilsam_amd_resident_steps(april_graph_t *graph, april_graph_cholesky_param_t *param, int n, int mode) { return asam::resident_steps(graph, param, n, mode); }
+int aprilsam_amd_resident_sync(april_graph_t *graph, april_graph_cholesky_param_t *param) { return asam::resident_sync(graph, param); }
+double aprilsam_amd_resident_chi2(april_graph_t *graph) { return asam::resident_chi2(graph); }
+int aprilsam_amd_resident_end(april_graph_t *graph, april_graph_cholesky_param_t *param) { return asam::resident_end(graph, param); }
+int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls, double *flops, double *bytes, const char **names) {
+    return asam::kernel_profile(param, ms, calls, flops, bytes, names);
+}
 const char *aprilsam_amd_version(void) { return "aprilsam_amd 0.1 (gfx950, multifrontal FP64)"; }
 void aprilsam_amd_free(void *p) { free(p); }
 

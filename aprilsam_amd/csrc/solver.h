@@ -19,6 +19,12 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param);
 void inc_solve_only(april_graph_t *g, april_graph_cholesky_param_t *param);
 double graph_chi2(april_graph_t *g);
 int batch_resident(april_graph_t *g, april_graph_cholesky_param_t *param, int iters, double *chi2_out, double *ms_out);
+int resident_begin(april_graph_t *g, april_graph_cholesky_param_t *param);
+int resident_steps(april_graph_t *g, april_graph_cholesky_param_t *param, int n, int mode);
+int resident_sync(april_graph_t *g, april_graph_cholesky_param_t *param);
+double resident_chi2(april_graph_t *g);
+int resident_end(april_graph_t *g, april_graph_cholesky_param_t *param);
+int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls, double *flops, double *bytes, const char **names);
 void drop_context(const april_graph_cholesky_param_t *p);
 void drop_graph_pack(const april_graph_t *g);
 bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out);

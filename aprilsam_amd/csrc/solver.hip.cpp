@@ -216,6 +216,8 @@ static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp) {
 // ------------------------------------------------------------------------------------------------------
 // solver context — one per april_graph_cholesky_param_t pointer
 // ------------------------------------------------------------------------------------------------------
+enum { K_LINEARIZE = 0, K_FRONT_SMALL, K_ASSEMBLE_BIG, K_PANEL_BIG, K_SYRK_BIG, K_BACKSOLVE, K_UPDATE, NKERN };
+static const char *const KNAMES[NKERN] = { "k_linearize", "k_front_small", "k_assemble_big", "k_panel_big", "k_syrk_big", "k_backsolve", "k_update_states" };
 struct Launch { int list_off, pre_off, n, grid; };     // offsets into the int launch-table buffer
 
 struct LevelPlan {
@@ -246,6 +248,9 @@ struct Context {
     aprilsam_amd_stats_t st{};
     hipEvent_t ev[8] = {};
     bool have_events = false;
+    // per-kernel HIP-event timing (instrumented passes only)
+    double k_ms[NKERN] = {}; long long k_calls[NKERN] = {};
+    std::vector<hipEvent_t> k_ev; std::vector<int> k_ids;
     // incremental bookkeeping (aprilsam.c:741-751, 566-575)
     bool have_fact = false;               // a batch factorisation exists (reference: param->chol != NULL)
     int batch_nodes = 0;                  // #nodes at the last batch step (those carry the Tikhonov term)
@@ -261,6 +266,8 @@ struct Context {
         gexec = nullptr;
         if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
         have_events = false;
+        for (auto &e : k_ev) (void)hipEventDestroy(e);
+        k_ev.clear();
     }
 };
 static std::unordered_map<const void *, std::unique_ptr<Context>> g_ctx;
@@ -376,41 +383,76 @@ static void set_small_attr() {
 
 // enqueue: linearise -> per level {assemble+factor} -> back substitution -> state update
 // ev != null: record stage events (0 start, 1 after linearise, 2 after factor, 3 after solve+update)
-static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t *ev, bool unary_at_lp = false) {
+// ktime: bracket EVERY kernel launch with its own HIP event pair on this stream (c.k_ev / c.k_ids)
+static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t *ev, bool unary_at_lp = false, bool ktime = false) {
     const Plan &P = c.plan;
     const int F = P.F, N = P.N;
+    size_t nev = 0;
+    if (ktime) c.k_ids.clear();
+    auto tic = [&](int id) {
+        if (!ktime) return;
+        if (c.k_ev.size() < nev + 2) { c.k_ev.resize(nev + 2); HIPCHECK(hipEventCreate(&c.k_ev[nev])); HIPCHECK(hipEventCreate(&c.k_ev[nev + 1])); }
+        HIPCHECK(hipEventRecord(c.k_ev[nev], s));
+        c.k_ids.push_back(id);
+    };
+    auto toc = [&]() { if (ktime) { HIPCHECK(hipEventRecord(c.k_ev[nev + 1], s)); nev += 2; } };
     if (ev) HIPCHECK(hipEventRecord(ev[0], s));
     HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 4, s));
+    tic(K_LINEARIZE);
     hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                        gp.d_lp.p, unary_at_lp ? gp.d_lp.p : gp.d_state.p, c.d_swap.p, c.d_H.p, c.d_G.p);
+    toc();
     if (ev) HIPCHECK(hipEventRecord(ev[1], s));
     for (int l = 0; l < P.nLevels; l++) {
         const LevelPlan &L = c.levels[l];
-        if (L.n_small)
+        if (L.n_small) {
+            tic(K_FRONT_SMALL);
             hipLaunchKernelGGL(k_front_small, dim3(L.n_small), dim3(TPB), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p,
                                c.d_H.p, c.d_G.p, c.d_bad.p);
+            toc();
+        }
         if (L.n_big) {
+            tic(K_ASSEMBLE_BIG);
             hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + L.asm_big.list_off,
                                c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p, c.d_G.p);
+            toc();
             for (size_t k = 0; k < L.panel.size(); k++) {
                 const Launch &pa = L.panel[k], &sy = L.syrk[k];
+                tic(K_PANEL_BIG);
                 hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off,
                                    pa.n, (int)k, c.d_pool.p, c.d_bad.p);
-                if (sy.grid > 0)
+                toc();
+                if (sy.grid > 0) {
+                    tic(K_SYRK_BIG);
                     hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off,
                                        sy.n, (int)k, c.d_pool.p);
+                    toc();
+                }
             }
         }
     }
     if (ev) HIPCHECK(hipEventRecord(ev[2], s));
     for (int l = P.nLevels - 1; l >= 0; l--) {
         const LevelPlan &L = c.levels[l];
+        tic(K_BACKSOLVE);
         hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
+        toc();
     }
     HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));     // NaN sentinel = "node skipped"
+    tic(K_UPDATE);
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
+    toc();
     if (ev) HIPCHECK(hipEventRecord(ev[3], s));
     HIPCHECK(hipGetLastError());
+}
+// after the stream was synchronised: fold the event pairs of the last instrumented enqueue into c.k_ms
+static void collect_kernel_times(Context &c) {
+    for (size_t i = 0; i < c.k_ids.size(); i++) {
+        float ms = 0;
+        HIPCHECK(hipEventElapsedTime(&ms, c.k_ev[2 * i], c.k_ev[2 * i + 1]));
+        c.k_ms[c.k_ids[i]] += ms; c.k_calls[c.k_ids[i]]++;
+    }
+    c.k_ids.clear();
 }
 
 // run the numeric phase, replaying a captured hipGraph when enabled
@@ -659,8 +701,10 @@ double graph_chi2(april_graph_t *g) {
     return device_chi2(gp);
 }
 
-// device-resident iterations: states never leave HBM between Gauss-Newton steps
-int batch_resident(april_graph_t *g, april_graph_cholesky_param_t *param, int iters, double *chi2_out, double *ms_out) {
+// ------------------------------------------------------------------------------------------------------
+// device-resident driver API: states never leave HBM between Gauss-Newton steps
+// ------------------------------------------------------------------------------------------------------
+int resident_begin(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0) return -1;
     ensure_device();
     std::lock_guard<std::mutex> lk(g_mu);
@@ -668,48 +712,124 @@ int batch_resident(april_graph_t *g, april_graph_cholesky_param_t *param, int it
     GraphPack &gp = pack_for(g);
     pack_factors(gp, g);
     pack_states(gp, g, false);
-    const int N = gp.N, F = gp.F;
     const bool reused = prepare_plan(c, gp, g);
     upload_factors(gp);
     set_lambda(c, gp, param->tikhanov);
-    hipStream_t s = gp.stream;
     if (!c.have_events) { for (auto &e : c.ev) HIPCHECK(hipEventCreate(&e)); c.have_events = true; }
-    if (chi2_out) chi2_out[0] = device_chi2(gp);
-    int rc = 0;
-    for (int it = 0; it < iters; it++) {
-        HIPCHECK(hipEventRecord(c.ev[4], s));
-        HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
-        run_numeric(c, gp, false);
-        HIPCHECK(hipEventRecord(c.ev[5], s));
-        HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
-        if (ms_out) { float ms = 0; HIPCHECK(hipEventElapsedTime(&ms, c.ev[4], c.ev[5])); ms_out[it] = ms; }
-        if (c.h_bad.p[0]) { rc = -2; break; }
-        if (chi2_out) chi2_out[it + 1] = device_chi2(gp);
-    }
-    c.st.not_spd = rc == -2;
-    c.st.n_nodes = N; c.st.n_factors = F; c.st.symbolic_reused = reused;
-    if (rc == 0) {
-        HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipMemcpyAsync(gp.h_lp.p, gp.d_lp.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
-        april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
-        for (int i = 0; i < N; i++) {
-            april_graph_node_t *n = ns[i];
-            n->UID = i;
-            memcpy(n->state, gp.h_state.p + (size_t)3 * i, 24);
-            memcpy(n->l_point, gp.h_lp.p + (size_t)3 * i, 24);
-            const double *dx = gp.h_dx.p + (size_t)3 * i;
-            if (!(std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2]))) memcpy(n->delta_X, dx, 24);
+    for (int k = 0; k < NKERN; k++) { c.k_ms[k] = 0; c.k_calls[k] = 0; }
+    c.st.n_nodes = gp.N; c.st.n_factors = gp.F; c.st.symbolic_reused = reused; c.st.not_spd = 0;
+    HIPCHECK(hipStreamSynchronize(gp.stream));
+    return 0;
+}
+// enqueue n iterations.  mode 0: asynchronous (hipGraph replay when enabled), returns at once;
+// mode 1: every kernel bracketed by HIP events on the solver stream, synchronises after each iteration.
+int resident_steps(april_graph_t *g, april_graph_cholesky_param_t *param, int n, int mode) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(param);
+    if (it == g_ctx.end() || !it->second->have_plan) return -1;
+    Context &c = *it->second;
+    GraphPack &gp = pack_for(g);
+    hipStream_t s = gp.stream;
+    const int N = gp.N;
+    HIPCHECK(hipSetDevice(g_device));
+    set_small_attr();
+    for (int i = 0; i < n; i++) {
+        HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));   // relinearise
+        if (mode == 1) {
+            enqueue_numeric(c, gp, s, nullptr, false, true);
+            HIPCHECK(hipStreamSynchronize(s));
+            collect_kernel_times(c);
+        } else {
+            run_numeric(c, gp, false);
         }
-        if (param->ordering) free(param->ordering);
-        param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
-        memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
-        param->nreordering = N; param->factor_num = F;
-        c.have_fact = true; c.batch_nodes = N; c.relin.assign(N, 0); c.start_over = 0;
     }
+    return 0;
+}
+int resident_sync(april_graph_t *g, april_graph_cholesky_param_t *param) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(param);
+    if (it == g_ctx.end()) return -1;
+    Context &c = *it->second;
+    GraphPack &gp = pack_for(g);
+    HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, gp.stream));
+    HIPCHECK(hipStreamSynchronize(gp.stream));
+    c.st.not_spd = c.h_bad.p[0] != 0;
+    return c.h_bad.p[0] ? -2 : 0;
+}
+double resident_chi2(april_graph_t *g) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return device_chi2(pack_for(g));
+}
+int resident_end(april_graph_t *g, april_graph_cholesky_param_t *param) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(param);
+    if (it == g_ctx.end()) return -1;
+    Context &c = *it->second;
+    GraphPack &gp = pack_for(g);
+    hipStream_t s = gp.stream;
+    const int N = gp.N, F = gp.F;
+    HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(gp.h_lp.p, gp.d_lp.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
+    for (int i = 0; i < N; i++) {
+        april_graph_node_t *n = ns[i];
+        n->UID = i;
+        memcpy(n->state, gp.h_state.p + (size_t)3 * i, 24);
+        memcpy(n->l_point, gp.h_lp.p + (size_t)3 * i, 24);
+        const double *dx = gp.h_dx.p + (size_t)3 * i;
+        if (!(std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2]))) memcpy(n->delta_X, dx, 24);
+    }
+    if (param->ordering) free(param->ordering);
+    param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
+    memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
+    param->nreordering = N; param->factor_num = F;
+    c.have_fact = true; c.batch_nodes = N; c.relin.assign(N, 0); c.start_over = 0;
+    return 0;
+}
+int batch_resident(april_graph_t *g, april_graph_cholesky_param_t *param, int iters, double *chi2_out, double *ms_out) {
+    int rc = resident_begin(g, param);
+    if (rc) return rc;
+    if (chi2_out) chi2_out[0] = resident_chi2(g);
+    for (int it = 0; it < iters && rc == 0; it++) {
+        const double t0 = now_ms();
+        resident_steps(g, param, 1, 0);
+        rc = resident_sync(g, param);
+        if (ms_out) ms_out[it] = now_ms() - t0;
+        if (rc == 0 && chi2_out) chi2_out[it + 1] = resident_chi2(g);
+    }
+    if (rc == 0) rc = resident_end(g, param);
     return rc;
+}
+// per-kernel profile of the instrumented passes since resident_begin + algorithmic work per ITERATION
+int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls, double *flops, double *bytes, const char **names) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(param);
+    if (it == g_ctx.end() || !it->second->have_plan) return -1;
+    Context &c = *it->second;
+    const Plan &P = c.plan;
+    for (int k = 0; k < NKERN; k++) { ms[k] = c.k_ms[k]; calls[k] = c.k_calls[k]; flops[k] = 0; bytes[k] = 0; if (names) names[k] = KNAMES[k]; }
+    const size_t small_max = (size_t)g_opt.small_lds_kb * 1024;
+    for (int t = 0; t < P.nF; t++) {
+        const double ns = 3.0 * P.f_nsb[t], nu = 3.0 * P.f_nub[t], R = P.rows(t), C = P.cols(t);
+        double fl = 0;                                          // sum_j c_j^2 over this front's columns (+ rhs row)
+        for (int q = 0; q < (int)ns; q++) { double cj = (ns - q) + nu + 1; fl += cj * cj; }
+        const bool small = ((size_t)R | 1) * (size_t)C * 8 <= small_max;
+        // algorithmic bytes of a front: its L panel + update block written once, children's updates read once
+        const double by = 8.0 * (ns * (ns + 1) / 2 + (nu + 1) * ns + (nu + 1) * (nu + 2) / 2);
+        if (small) { flops[K_FRONT_SMALL] += fl; bytes[K_FRONT_SMALL] += by; }
+        else { flops[K_SYRK_BIG] += fl; bytes[K_SYRK_BIG] += by; }
+        bytes[K_BACKSOLVE] += 8.0 * (ns * (ns + 1) / 2 + nu * ns) + 16.0 * (ns + nu);
+        flops[K_BACKSOLVE] += 2.0 * (ns * (ns + 1) / 2 + nu * ns);
+    }
+    // SURVEY.md section 8(d) assembly bytes: factor records + poses read, contribution blocks written
+    int F2 = 0, F1 = 0;
+    for (int f = 0; f < P.F; f++) (c.pat[2 * f + 1] >= 0 ? F2 : F1)++;
+    bytes[K_LINEARIZE] = F2 * 152.0 + F1 * 124.0 + 8.0 * (27.0 * F2 + 9.0 * F1 + 6.0 * F2 + 3.0 * F1);
+    flops[K_LINEARIZE] = 150.0 * F2 + 40.0 * F1;
+    bytes[K_UPDATE] = 8.0 * 3 * P.N * 4;
+    return NKERN;
 }
 
 int api_device_count() { return device_count(); }

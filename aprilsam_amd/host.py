@@ -66,6 +66,12 @@ class SolverLib:
             d.aprilsam_amd_set_option.argtypes = [C.c_char_p, C.c_double]
             d.aprilsam_amd_batch_resident.argtypes = [C.POINTER(abi.Graph), C.POINTER(abi.CholeskyParam),
                                                       C.c_int, _dp, _dp]
+            for nm in ("begin", "sync", "end"):
+                getattr(d, f"aprilsam_amd_resident_{nm}").argtypes = [C.POINTER(abi.Graph), C.POINTER(abi.CholeskyParam)]
+            d.aprilsam_amd_resident_steps.argtypes = [C.POINTER(abi.Graph), C.POINTER(abi.CholeskyParam), C.c_int, C.c_int]
+            d.aprilsam_amd_resident_chi2.argtypes = [C.POINTER(abi.Graph)]
+            d.aprilsam_amd_resident_chi2.restype = C.c_double
+            d.aprilsam_amd_set_device.argtypes = [C.c_int]
             d.aprilsam_amd_make_lattice.argtypes = [C.POINTER(abi.Graph), C.c_int]
             d.aprilsam_amd_lattice_arrays.argtypes = [C.c_int, _dp, _ip, _ip, _dp, _dp]
             d.aprilsam_amd_graph_from_arrays.argtypes = [C.POINTER(abi.Graph), C.c_int, _dp, C.c_int, _ip, _ip, _dp, _dp]

@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json metric on MI355X: Gauss-Newton iterations/s (+ factorise ms) on M3500, chi^2 matched.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1 is launched by torch.distributed.run)
+
+A "step" is one batch Gauss-Newton iteration of the hot path (relinearise -> linearise -> assemble ->
+factorise -> solve -> update) over the whole M3500 graph (3500 poses, 5453 xyt factors + the prior), with
+the node states and factor data already resident in HBM when the timed region starts; chi^2 is evaluated
+outside the timed region, as examples/aprilsam_demo.c:103-107,229 does.  M3500 is far too small to shard
+("replicas only"), so with N GPUs every rank solves its own replica: weak scaling,
+value = N * K / max-over-ranks wall time.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     — dominant kernel (by HIP-event time) of an instrumented pass of the same K steps: every
+                 kernel launch bracketed by an event pair on the solver's own stream
+  cpu_baseline — the reference CPU path (oracle/_ref, unmodified AprilSAM built from source) or, if it
+                 did not travel, the C port (oracle/liboracle.so), timed on this box's host, 1 thread
+  parity       — max relative chi^2 error of 10 iterations vs the reference golden (tests/golden)
+  lattice100k  — config 4 (99 856 poses) ms/iteration measured the same way, for BASELINE.md's second target
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak; HBM peak from MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+FLOP_KERNELS = {"k_front_small", "k_syrk_big", "k_panel_big"}
+
+
+def kernel_profile(lib, p):
+    ms = (C.c_double * 8)(); calls = (C.c_longlong * 8)(); fl = (C.c_double * 8)(); by = (C.c_double * 8)()
+    names = (C.c_char_p * 8)()
+    n = lib.dll.aprilsam_amd_kernel_profile(p.ptr, ms, calls, fl, by, names)
+    return [dict(name=names[k].decode(), ms=ms[k], calls=calls[k], flops=fl[k], bytes=by[k]) for k in range(n)]
+
+
+def timed_steps(lib, g, p, K, sync_all, barrier):
+    import torch
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lib.dll.aprilsam_amd_resident_steps(g.ptr, p.ptr, K, 0)
+    rc = lib.dll.aprilsam_amd_resident_sync(g.ptr, p.ptr)
+    torch.cuda.synchronize(); barrier()
+    t1 = time.perf_counter()
+    assert rc == 0, "not positive definite"
+    return sync_all(t1 - t0)
+
+
+def cpu_baseline(arrays, budget_s=12.0):
+    """reference CPU april_graph_cholesky on this host, single thread; bounded sample of whole iterations"""
+    from aprilsam_amd import host
+    from tests.support.oracle_binding import REFLIB, Oracle
+    if os.path.exists(REFLIB):
+        ref = host.SolverLib(REFLIB)
+        g = ref.new_graph(); g.build_from_arrays(*arrays); p = ref.new_param()
+        g.cholesky(p)                                     # warm-up (first call also pays page faults)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or n < 3:
+            g.cholesky(p); n += 1
+        dt = time.perf_counter() - t0
+        p.destroy(); g.destroy()
+        kind = "reference"
+    else:
+        orc = Oracle()
+        s, fa, fb, z, W = arrays
+        s = np.array(s, float)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or n < 3:
+            s, _, _ = orc.batch_step(s, fa, fb, z, W); n += 1
+        dt = time.perf_counter() - t0
+        kind = "port"
+    return dict(value=n / dt, unit="GN iterations/s", cores=1, kind=kind, ms_per_iter=1e3 * dt / n,
+                sample=f"{n} consecutive batch iterations of the same M3500 graph ({dt:.1f} s of CPU time), "
+                       f"wall clock around the solver call only")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lattice", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as ge
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.barrier()
+
+        def barrier():
+            dist.barrier()
+
+        def sync_all(dt):
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+    else:
+        torch.cuda.set_device(0)
+
+        def barrier():
+            pass
+
+        def sync_all(dt):
+            return dt
+    from aprilsam_amd import datasets, host
+    lib = host.SolverLib()
+    lib.dll.aprilsam_amd_set_device(local)
+    arrays = datasets.m3500_batch()
+
+    # ---- parity gate on this very build: 10 iterations vs the reference golden -----------------------------
+    G = np.load(os.path.join(ROOT, "tests", "golden", "m3500_batch.npz"))
+    g = lib.new_graph(); g.build_from_arrays(*arrays); p = lib.new_param()
+    chi2, _ = g.batch_resident(p, 10)
+    chi2_err = float(np.max(np.abs(chi2 - G["chi2"]) / G["chi2"]))
+    state_err = float(np.max(np.abs(g.states() - G["final_states"])))
+    p.destroy(); g.destroy()
+    assert chi2_err < 1e-6, f"parity gate failed: chi2 relative error {chi2_err}"
+
+    # ---- timed region ------------------------------------------------------------------------------------------
+    g = lib.new_graph(); g.build_from_arrays(*arrays); p = lib.new_param()
+    t0 = time.perf_counter()
+    assert lib.dll.aprilsam_amd_resident_begin(g.ptr, p.ptr) == 0
+    first_call_ms = (time.perf_counter() - t0) * 1e3            # pack + ordering + symbolic + upload
+    lib.dll.aprilsam_amd_resident_steps(g.ptr, p.ptr, a.warmup, 0)
+    lib.dll.aprilsam_amd_resident_sync(g.ptr, p.ptr)
+    dt = timed_steps(lib, g, p, a.steps, sync_all, barrier)
+    ms_per_step = 1e3 * dt / a.steps
+    value = world * a.steps / dt
+
+    # ---- instrumented pass: same K steps, every kernel launch timed with HIP events on the solver stream ----
+    lib.dll.aprilsam_amd_resident_steps(g.ptr, p.ptr, a.steps, 1)
+    prof = kernel_profile(lib, p)
+    stats = p.stats()
+    lib.dll.aprilsam_amd_resident_end(g.ptr, p.ptr)
+    p.destroy(); g.destroy()
+    for k in prof:
+        k["ms_per_iter"] = k["ms"] / a.steps; k["launches_per_iter"] = k["calls"] / a.steps
+    dom = max(prof, key=lambda k: k["ms"])
+    dur_s = dom["ms_per_iter"] * 1e-3
+    if dom["name"] in FLOP_KERNELS:
+        ach = dom["flops"] / dur_s / 1e12
+        roof = dict(bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS)
+    else:
+        ach = dom["bytes"] / dur_s / 1e9
+        roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
+    roof.update(kernel=dom["name"], traffic=None, avg_launch_us=1e3 * dom["ms"] / max(1, dom["calls"]),
+                launches_per_step=dom["launches_per_iter"], kernel_ms_per_step=dom["ms_per_iter"],
+                algorithmic_work_per_step=dom["flops"] if dom["name"] in FLOP_KERNELS else dom["bytes"],
+                measured="HIP events around every launch of this kernel on the solver stream, instrumented pass of the same K steps")
+    factorise_ms = sum(k["ms_per_iter"] for k in prof if k["name"] in ("k_front_small", "k_assemble_big", "k_panel_big", "k_syrk_big"))
+
+    out = {
+        "metric": "Gauss-Newton iterations/sec + factorise ms on M3500 (chi2 match <=1e-6)",
+        "value": value, "unit": "GN iterations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "M3500 (reference data file, committed as fixture); synthetic only in `lattice100k`",
+        "config": {"workload": "M3500 batch april_graph_cholesky, 1 replica per GPU (3500 poses, 5454 factors, n=10500)",
+                   "parallelism": f"replicas x{world}" if world > 1 else "single GPU",
+                   "fronts": stats["n_fronts"], "levels": stats["n_levels"], "nnz_L": stats["nnz_L"],
+                   "sum_cj2": stats["flops_factor"], "leaf_nodes": 16},
+        "factorise_ms": factorise_ms,
+        "first_call_ms_incl_symbolic": first_call_ms,
+        "parity": {"chi2_max_relerr_10_iters": chi2_err, "max_abs_state_err": state_err, "bar": 1e-6},
+        "roofline": roof,
+        "kernels_ms_per_step": {k["name"]: round(k["ms_per_iter"], 5) for k in prof},
+        "kernel_launches_per_step": {k["name"]: k["launches_per_iter"] for k in prof},
+    }
+    if rank == 0 and world == 1 and not a.no_lattice:
+        try:
+            arr = lib.lattice_arrays(316)
+            g = lib.new_graph(); g.build_from_arrays(*arr); p = lib.new_param()
+            t0 = time.perf_counter()
+            lib.dll.aprilsam_amd_resident_begin(g.ptr, p.ptr)
+            sym_ms = (time.perf_counter() - t0) * 1e3
+            c0 = lib.dll.aprilsam_amd_resident_chi2  # noqa
+            lib.dll.aprilsam_amd_resident_chi2.restype = C.c_double
+            chi0 = lib.dll.aprilsam_amd_resident_chi2(g.ptr)
+            lib.dll.aprilsam_amd_resident_steps(g.ptr, p.ptr, 1, 0); lib.dll.aprilsam_amd_resident_sync(g.ptr, p.ptr)
+            chi1 = lib.dll.aprilsam_amd_resident_chi2(g.ptr)
+            ks = 10
+            dtl = timed_steps(lib, g, p, ks, lambda x: x, lambda: None)
+            lib.dll.aprilsam_amd_resident_steps(g.ptr, p.ptr, 3, 1)
+            lp = kernel_profile(lib, p); ls = p.stats()
+            out["lattice100k"] = {
+                "workload": "synthetic 316x316 Manhattan lattice, 99856 poses / 397531 factors (config 4)",
+                "ms_per_step": 1e3 * dtl / ks, "first_call_ms_incl_symbolic": sym_ms,
+                "chi2_0": chi0, "chi2_after_1": chi1,
+                "chi2_relerr_vs_reference": [abs(chi0 - 23540091.69690116) / 23540091.69690116, abs(chi1 - 460825.57393385) / 460825.57393385],
+                "reference_cpu_s_per_iter_survey_container": 44.8,
+                "nnz_L": ls["nnz_L"], "sum_cj2": ls["flops_factor"], "fronts": ls["n_fronts"], "levels": ls["n_levels"],
+                "kernels_ms_per_step": {k["name"]: round(k["ms"] / 3, 4) for k in lp},
+                "factor_tflops": ls["flops_factor"] / (1e-3 * sum(k["ms"] / 3 for k in lp if k["name"] in ("k_front_small", "k_assemble_big", "k_panel_big", "k_syrk_big"))) / 1e12,
+            }
+            lib.dll.aprilsam_amd_resident_end(g.ptr, p.ptr)
+            p.destroy(); g.destroy()
+        except Exception as e:   # the headline line must survive a failure of the extra
+            out["lattice100k"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(arrays)
+        out["cpu_baseline"]["host"] = f"{os.cpu_count()} logical cores visible; reference is single-threaded"
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -207,6 +207,22 @@ int aprilsam_amd_set_option(const char *name, double value);
 int aprilsam_amd_batch_resident(april_graph_t *graph, april_graph_cholesky_param_t *param, int iters,
                                 double *chi2_out, double *ms_out);
 
+/* The same, in pieces (what bench.py times): begin = pack + plan + upload (states now resident in HBM);
+ * steps(n, mode) enqueues n Gauss-Newton iterations on the solver's HIP stream — mode 0 asynchronously
+ * (hipGraph replay), mode 1 with every kernel launch bracketed by a HIP event pair on that stream and a
+ * synchronisation per iteration; sync waits and returns -2 if a pivot was not positive; chi2 evaluates
+ * chi^2 of the resident states; end writes the states back into the graph's node objects. */
+int    aprilsam_amd_resident_begin(april_graph_t *graph, april_graph_cholesky_param_t *param);
+int    aprilsam_amd_resident_steps(april_graph_t *graph, april_graph_cholesky_param_t *param, int n, int mode);
+int    aprilsam_amd_resident_sync(april_graph_t *graph, april_graph_cholesky_param_t *param);
+double aprilsam_amd_resident_chi2(april_graph_t *graph);
+int    aprilsam_amd_resident_end(april_graph_t *graph, april_graph_cholesky_param_t *param);
+/* Per-kernel totals of the mode-1 passes since resident_begin (ms, launches) and the ALGORITHMIC flops /
+ * bytes one iteration asks of each kernel (SURVEY.md §8(d) conventions).  Arrays of 8; returns the
+ * number of kernels filled; names[k] points at static strings. */
+int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls,
+                                double *flops, double *bytes, const char **names);
+
 /* ---- host-logic introspection (no GPU needed): ordering + symbolic analysis of a graph -------- */
 typedef struct aprilsam_amd_plan aprilsam_amd_plan_t;   /* opaque */
 aprilsam_amd_plan_t *aprilsam_amd_plan_create(int n_nodes, int n_factors, const int *factor_nodes /* 2 per factor, -1 for unary */,
