@@ -62,6 +62,7 @@ int aprilsam_amd_resident_end(april_graph_t *graph, april_graph_cholesky_param_t
 int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls, double *flops, double *bytes, const char **names) {
     return asam::kernel_profile(param, ms, calls, flops, bytes, names);
 }
+int aprilsam_amd_debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts) { return asam::debug_front_times(param, out, n_fronts); }
 const char *aprilsam_amd_version(void) { return "aprilsam_amd 0.1 (gfx950, multifrontal FP64)"; }
 void aprilsam_amd_free(void *p) { free(p); }
 

@@ -11,6 +11,7 @@ struct Options {
     int device_timing = 0;        // record HIP events per stage (disables graph replay for that call)
     int trust_factor_cache = 1;   // z/W of factors already packed are treated as immutable
     int small_lds_kb = 100;       // fronts whose LDS image fits run in the single-workgroup LDS kernel
+    int medium_lds_kb = 0;        // fronts whose 32-column panel fits run in the single-workgroup L2 kernel (0 = off)
 };
 extern Options g_opt;
 
@@ -28,6 +29,7 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
 void drop_context(const april_graph_cholesky_param_t *p);
 void drop_graph_pack(const april_graph_t *g);
 bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out);
+int debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts);
 int api_device_count();
 int api_set_device(int d);
 int api_set_option(const char *name, double v);

@@ -59,6 +59,7 @@ static void load_env_options() {
         v = g_opt.device_timing; envd("APRILSAM_AMD_DEVICE_TIMING", &v); g_opt.device_timing = (int)v;
         v = g_opt.trust_factor_cache; envd("APRILSAM_AMD_TRUST_FACTOR_CACHE", &v); g_opt.trust_factor_cache = (int)v;
         v = g_opt.small_lds_kb; envd("APRILSAM_AMD_SMALL_LDS_KB", &v); g_opt.small_lds_kb = (int)v;
+        v = g_opt.medium_lds_kb; envd("APRILSAM_AMD_MEDIUM_LDS_KB", &v); g_opt.medium_lds_kb = (int)v;
     });
 }
 
@@ -216,13 +217,14 @@ static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp) {
 // ------------------------------------------------------------------------------------------------------
 // solver context — one per april_graph_cholesky_param_t pointer
 // ------------------------------------------------------------------------------------------------------
-enum { K_LINEARIZE = 0, K_FRONT_SMALL, K_ASSEMBLE_BIG, K_PANEL_BIG, K_SYRK_BIG, K_BACKSOLVE, K_UPDATE, NKERN };
-static const char *const KNAMES[NKERN] = { "k_linearize", "k_front_small", "k_assemble_big", "k_panel_big", "k_syrk_big", "k_backsolve", "k_update_states" };
+enum { K_LINEARIZE = 0, K_FRONT_SMALL, K_FRONT_MEDIUM, K_ASSEMBLE_BIG, K_PANEL_BIG, K_SYRK_BIG, K_BACKSOLVE, K_UPDATE, NKERN };
+static const char *const KNAMES[NKERN] = { "k_linearize", "k_front_small", "k_front_medium", "k_assemble_big", "k_panel_big", "k_syrk_big", "k_backsolve", "k_update_states" };
 struct Launch { int list_off, pre_off, n, grid; };     // offsets into the int launch-table buffer
 
 struct LevelPlan {
     int small_off = 0, n_small = 0; size_t small_lds = 0;      // fronts handled by k_front_small
-    int n_big = 0;
+    int med_off = 0, n_med = 0; size_t med_lds = 0;            // fronts handled by k_front_medium
+    int n_big = 0; size_t asm_lds = 0;
     Launch asm_big{};                                          // k_assemble_big
     std::vector<Launch> panel, syrk;                           // per panel step
     int all_off = 0, n_all = 0; size_t solve_lds = 0;          // every front (k_backsolve)
@@ -234,14 +236,15 @@ struct Context {
     std::vector<int> pat;                 // factor node ids the plan was built for (2 per factor)
     int patN = 0;
     // device copies of the plan
-    DBuf<int> d_i32; DBuf<long long> d_i64; DBuf<double> d_lambda;
+    DBuf<int> d_i32; DBuf<FrontDesc> d_fd; DBuf<DestRec> d_dest; DBuf<ChildRec> d_child; DBuf<double> d_lambda;
     DevPlan dp{};
     DBuf<int> d_tab;                      // launch tables
     std::vector<LevelPlan> levels;
     DBuf<unsigned char> d_swap;
     DBuf<int> d_pos;
+    DBuf<long long> d_prof;
     // numeric state
-    DBuf<double> d_pool, d_H, d_G, d_x;
+    DBuf<double> d_pool, d_H, d_x;
     DBuf<int> d_bad;
     HBuf<int> h_bad;
     std::vector<double> h_lambda;
@@ -260,8 +263,8 @@ struct Context {
     hipGraphExec_t gexec = nullptr;
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
     void release() {
-        d_i32.release(); d_i64.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
-        d_pool.release(); d_H.release(); d_G.release(); d_x.release(); d_bad.release(); h_bad.release();
+        d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
+        d_pool.release(); d_H.release(); d_x.release(); d_bad.release(); h_bad.release();
         if (gexec) (void)hipGraphExecDestroy(gexec);
         gexec = nullptr;
         if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
@@ -294,27 +297,41 @@ bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out)
 static void upload_plan(Context &c, hipStream_t s) {
     const Plan &P = c.plan;
     if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
-    // ---- int32 / int64 arrays, concatenated -------------------------------------------------------------
-    std::vector<int> i32; std::vector<long long> i64;
+    // ---- descriptors + index arrays ----------------------------------------------------------------------------
+    std::vector<FrontDesc> fd(P.nF);
+    std::vector<ChildRec> ch(std::max<size_t>(1, P.ch_idx.size()));
+    for (int t = 0; t < P.nF; t++) {
+        FrontDesc &d = fd[t];
+        memset(&d, 0, sizeof(d));
+        d.off = P.f_off[t]; d.nsb = P.f_nsb[t]; d.nub = P.f_nub[t]; d.first = P.f_first[t];
+        d.dest_begin = P.dest_front_ptr[t]; d.dest_end = P.dest_front_ptr[t + 1];
+        d.ch_begin = P.ch_ptr[t]; d.ch_end = P.ch_ptr[t + 1];
+        d.rows_begin = (int)P.f_rows_ptr[t]; d.parent = P.f_parent[t];
+    }
+    for (size_t k = 0; k < P.ch_idx.size(); k++) {
+        const int cfr = P.ch_idx[k];
+        ChildRec &r = ch[k];
+        r.cR = P.rows(cfr); r.cnu = P.f_nub[cfr];
+        r.uoff = P.f_off[cfr] + (long long)(3 * P.f_nsb[cfr]) * r.cR + 3 * P.f_nsb[cfr];
+        r.rel_begin = (int)P.f_rows_ptr[cfr]; r.pad = 0;
+    }
+    std::vector<int> i32;
     auto put32 = [&](const std::vector<int> &v) { size_t o = i32.size(); i32.insert(i32.end(), v.begin(), v.end()); if (v.empty()) i32.push_back(0); return o; };
-    auto put64 = [&](const std::vector<int64_t> &v) { size_t o = i64.size(); for (auto x : v) i64.push_back((long long)x); if (v.empty()) i64.push_back(0); return o; };
-    size_t o_first = put32(P.f_first), o_nsb = put32(P.f_nsb), o_nub = put32(P.f_nub), o_par = put32(P.f_parent);
-    size_t o_rows = put32(P.f_rows), o_rel = put32(P.f_rel), o_chp = put32(P.ch_ptr), o_chi = put32(P.ch_idx);
-    size_t o_bfp = put32(P.bd_front_ptr), o_br = put32(P.bd_row), o_bc = put32(P.bd_col), o_bsp = put32(P.bd_src_ptr), o_bs = put32(P.bd_src);
-    size_t o_rfp = put32(P.rd_front_ptr), o_rc = put32(P.rd_col), o_rsp = put32(P.rd_src_ptr), o_rs = put32(P.rd_src);
-    size_t o_off = put64(P.f_off), o_rp = put64(P.f_rows_ptr);
-    c.d_i32.need(i32.size()); c.d_i64.need(i64.size());
+    size_t o_rows = put32(P.f_rows), o_rel = put32(P.f_rel), o_sb = put32(P.slot_blk), o_sr = put32(P.slot_rhs);
+    c.d_i32.need(i32.size()); c.d_fd.need(fd.size()); c.d_child.need(ch.size()); c.d_dest.need(std::max<size_t>(1, P.dest.size()));
     HIPCHECK(hipMemcpyAsync(c.d_i32.p, i32.data(), i32.size() * 4, hipMemcpyHostToDevice, s));
-    HIPCHECK(hipMemcpyAsync(c.d_i64.p, i64.data(), i64.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(c.d_fd.p, fd.data(), fd.size() * sizeof(FrontDesc), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipMemcpyAsync(c.d_child.p, ch.data(), ch.size() * sizeof(ChildRec), hipMemcpyHostToDevice, s));
+    static_assert(sizeof(DestRec) == sizeof(Plan::DestRec), "DestRec layout");
+    if (!P.dest.empty()) HIPCHECK(hipMemcpyAsync(c.d_dest.p, P.dest.data(), P.dest.size() * sizeof(DestRec), hipMemcpyHostToDevice, s));
     c.d_lambda.need(std::max(1, P.N));
     DevPlan &d = c.dp;
     d.nF = P.nF;
-    d.f_first = c.d_i32.p + o_first; d.f_nsb = c.d_i32.p + o_nsb; d.f_nub = c.d_i32.p + o_nub; d.f_parent = c.d_i32.p + o_par;
-    d.f_rows = c.d_i32.p + o_rows; d.f_rel = c.d_i32.p + o_rel; d.ch_ptr = c.d_i32.p + o_chp; d.ch_idx = c.d_i32.p + o_chi;
-    d.bd_front_ptr = c.d_i32.p + o_bfp; d.bd_row = c.d_i32.p + o_br; d.bd_col = c.d_i32.p + o_bc; d.bd_src_ptr = c.d_i32.p + o_bsp; d.bd_src = c.d_i32.p + o_bs;
-    d.rd_front_ptr = c.d_i32.p + o_rfp; d.rd_col = c.d_i32.p + o_rc; d.rd_src_ptr = c.d_i32.p + o_rsp; d.rd_src = c.d_i32.p + o_rs;
-    d.f_off = c.d_i64.p + o_off; d.f_rows_ptr = c.d_i64.p + o_rp;
+    d.fd = c.d_fd.p; d.dest = c.d_dest.p; d.child = c.d_child.p;
+    d.f_rows = c.d_i32.p + o_rows; d.f_rel = c.d_i32.p + o_rel; d.slot_blk = c.d_i32.p + o_sb; d.slot_rhs = c.d_i32.p + o_sr;
     d.lambda = c.d_lambda.p;
+    d.prof = nullptr;
+    if (getenv("APRILSAM_AMD_KPROF")) { c.d_prof.need((size_t)8 * P.nF); HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)64 * P.nF, s)); d.prof = c.d_prof.p; }
     c.d_swap.need(std::max(1, P.F)); c.d_pos.need(std::max(1, P.N));
     HIPCHECK(hipMemcpyAsync(c.d_swap.p, P.fac_swap.data(), P.F, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_pos.p, P.pos.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
@@ -322,24 +339,27 @@ static void upload_plan(Context &c, hipStream_t s) {
     // ---- launch tables -------------------------------------------------------------------------------------
     std::vector<int> tab;
     c.levels.assign(P.nLevels, LevelPlan());
-    const size_t small_max = (size_t)g_opt.small_lds_kb * 1024;
+    const size_t small_max = (size_t)g_opt.small_lds_kb * 1024, med_max = (size_t)g_opt.medium_lds_kb * 1024;
     for (int l = 0; l < P.nLevels; l++) {
         LevelPlan &L = c.levels[l];
-        std::vector<int> small, big;
+        std::vector<int> small, med, big;
         size_t maxm = 0;
         for (int k = P.lev_ptr[l]; k < P.lev_ptr[l + 1]; k++) {
             int t = P.lev_fronts[k];
-            size_t R = P.rows(t), C = P.cols(t);
-            size_t lds = (R | 1) * C * 8;
-            maxm = std::max(maxm, C);
-            if (lds <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds); }
-            else big.push_back(t);
+            const int R = P.rows(t), C = P.cols(t);
+            maxm = std::max<size_t>(maxm, C);
+            const size_t lds_s = small_front_lds(R, C), lds_m = medium_front_lds(R);
+            if (lds_s <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); }
+            else if (lds_m <= med_max) { med.push_back(t); L.med_lds = std::max(L.med_lds, lds_m); }
+            else { big.push_back(t); L.asm_lds = std::max(L.asm_lds, scratch_bytes(R)); }
         }
         L.all_off = (int)tab.size(); L.n_all = P.lev_ptr[l + 1] - P.lev_ptr[l];
         tab.insert(tab.end(), P.lev_fronts.begin() + P.lev_ptr[l], P.lev_fronts.begin() + P.lev_ptr[l + 1]);
         L.solve_lds = (maxm + NB + 8) * 8;
         L.small_off = (int)tab.size(); L.n_small = (int)small.size();
         tab.insert(tab.end(), small.begin(), small.end());
+        L.med_off = (int)tab.size(); L.n_med = (int)med.size();
+        tab.insert(tab.end(), med.begin(), med.end());
         L.n_big = (int)big.size();
         if (big.empty()) continue;
         std::sort(big.begin(), big.end(), [&](int a, int b) { return P.f_nsb[a] != P.f_nsb[b] ? P.f_nsb[a] > P.f_nsb[b] : a < b; });
@@ -367,7 +387,7 @@ static void upload_plan(Context &c, hipStream_t s) {
     HIPCHECK(hipStreamSynchronize(s));      // host vectors above go out of scope
 
     c.d_pool.need((size_t)std::max<int64_t>(P.pool_doubles, 1));
-    c.d_H.need((size_t)27 * std::max(1, P.F)); c.d_G.need((size_t)6 * std::max(1, P.F)); c.d_x.need((size_t)3 * std::max(1, P.N));
+    c.d_H.need((size_t)9 * std::max(1, P.n_slots)); c.d_x.need((size_t)3 * std::max(1, P.N));
     c.d_bad.need(4); c.h_bad.need(4);
     c.st.n_fronts = P.nF; c.st.n_levels = P.nLevels; c.st.max_front_rows = P.max_rows;
     c.st.nnz_L = P.nnzL; c.st.flops_factor = P.flops; c.st.bytes_fronts = 8.0 * (double)P.pool_doubles;
@@ -377,7 +397,9 @@ static void set_small_attr() {
     static std::once_flag once;
     std::call_once(once, [] {
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_front_medium, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_assemble_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
 }
 
@@ -398,9 +420,10 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     auto toc = [&]() { if (ktime) { HIPCHECK(hipEventRecord(c.k_ev[nev + 1], s)); nev += 2; } };
     if (ev) HIPCHECK(hipEventRecord(ev[0], s));
     HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 4, s));
+    if (c.dp.prof) HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)64 * P.nF, s));
     tic(K_LINEARIZE);
     hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                       gp.d_lp.p, unary_at_lp ? gp.d_lp.p : gp.d_state.p, c.d_swap.p, c.d_H.p, c.d_G.p);
+                       gp.d_lp.p, unary_at_lp ? gp.d_lp.p : gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
     toc();
     if (ev) HIPCHECK(hipEventRecord(ev[1], s));
     for (int l = 0; l < P.nLevels; l++) {
@@ -408,13 +431,19 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
         if (L.n_small) {
             tic(K_FRONT_SMALL);
             hipLaunchKernelGGL(k_front_small, dim3(L.n_small), dim3(TPB), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p,
-                               c.d_H.p, c.d_G.p, c.d_bad.p);
+                               c.d_H.p, c.d_bad.p);
+            toc();
+        }
+        if (L.n_med) {
+            tic(K_FRONT_MEDIUM);
+            hipLaunchKernelGGL(k_front_medium, dim3(L.n_med), dim3(TPB_MED), L.med_lds, s, c.dp, c.d_tab.p + L.med_off, c.d_pool.p,
+                               c.d_H.p, c.d_bad.p);
             toc();
         }
         if (L.n_big) {
             tic(K_ASSEMBLE_BIG);
-            hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + L.asm_big.list_off,
-                               c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p, c.d_G.p);
+            hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
+                               c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
             toc();
             for (size_t k = 0; k < L.panel.size(); k++) {
                 const Launch &pa = L.panel[k], &sy = L.syrk[k];
@@ -810,15 +839,16 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
     Context &c = *it->second;
     const Plan &P = c.plan;
     for (int k = 0; k < NKERN; k++) { ms[k] = c.k_ms[k]; calls[k] = c.k_calls[k]; flops[k] = 0; bytes[k] = 0; if (names) names[k] = KNAMES[k]; }
-    const size_t small_max = (size_t)g_opt.small_lds_kb * 1024;
+    const size_t small_max = (size_t)g_opt.small_lds_kb * 1024, med_max = (size_t)g_opt.medium_lds_kb * 1024;
     for (int t = 0; t < P.nF; t++) {
         const double ns = 3.0 * P.f_nsb[t], nu = 3.0 * P.f_nub[t], R = P.rows(t), C = P.cols(t);
         double fl = 0;                                          // sum_j c_j^2 over this front's columns (+ rhs row)
         for (int q = 0; q < (int)ns; q++) { double cj = (ns - q) + nu + 1; fl += cj * cj; }
-        const bool small = ((size_t)R | 1) * (size_t)C * 8 <= small_max;
+        const bool small = small_front_lds((int)R, (int)C) <= small_max, medium = !small && medium_front_lds((int)R) <= med_max;
         // algorithmic bytes of a front: its L panel + update block written once, children's updates read once
         const double by = 8.0 * (ns * (ns + 1) / 2 + (nu + 1) * ns + (nu + 1) * (nu + 2) / 2);
         if (small) { flops[K_FRONT_SMALL] += fl; bytes[K_FRONT_SMALL] += by; }
+        else if (medium) { flops[K_FRONT_MEDIUM] += fl; bytes[K_FRONT_MEDIUM] += by; }
         else { flops[K_SYRK_BIG] += fl; bytes[K_SYRK_BIG] += by; }
         bytes[K_BACKSOLVE] += 8.0 * (ns * (ns + 1) / 2 + nu * ns) + 16.0 * (ns + nu);
         flops[K_BACKSOLVE] += 2.0 * (ns * (ns + 1) / 2 + nu * ns);
@@ -832,6 +862,16 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
     return NKERN;
 }
 
+// debug: copy the per-front clock stamps (8 per front) written when APRILSAM_AMD_KPROF is set
+int debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(param);
+    if (it == g_ctx.end() || !it->second->d_prof.p) return -1;
+    HIPCHECK(hipDeviceSynchronize());
+    int n = std::min(n_fronts, it->second->plan.nF);
+    HIPCHECK(hipMemcpy(out, it->second->d_prof.p, (size_t)64 * n, hipMemcpyDeviceToHost));
+    return n;
+}
 int api_device_count() { return device_count(); }
 int api_set_device(int d) {
     int n = device_count();
@@ -848,6 +888,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "device_timing") g_opt.device_timing = (int)v;
     else if (k == "trust_factor_cache") g_opt.trust_factor_cache = (int)v;
     else if (k == "small_lds_kb") g_opt.small_lds_kb = (int)v;
+    else if (k == "medium_lds_kb") g_opt.medium_lds_kb = (int)v;
     else return -1;
     return 0;
 }

@@ -163,6 +163,25 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
     compress(bd, P.bd_front_ptr, P.bd_row, P.bd_col, P.bd_src_ptr, P.bd_src);
     compress(rd, P.rd_front_ptr, dummy_row, P.rd_col, P.rd_src_ptr, P.rd_src);
 
+    // ---- unified destination records + contribution slots (device layout) --------------------------------
+    {
+        struct U { int front, col, row, src, rhs; };
+        std::vector<U> all; all.reserve(bd.size() + rd.size());
+        for (const Dest &d : bd) all.push_back({ d.front, d.col, d.row, d.src, 0 });
+        for (const Dest &d : rd) all.push_back({ d.front, d.col, P.f_nsb[d.front] + P.f_nub[d.front], d.src, 1 });
+        std::sort(all.begin(), all.end(), [](const U &x, const U &y) { return std::tie(x.front, x.col, x.row, x.src) < std::tie(y.front, y.col, y.row, y.src); });
+        P.dest_front_ptr.assign(nT + 1, 0); P.dest.clear();
+        P.slot_blk.assign((size_t)3 * F, -1); P.slot_rhs.assign((size_t)2 * F, -1);
+        for (size_t i = 0; i < all.size(); i++) {
+            const bool fresh = i == 0 || all[i].front != all[i - 1].front || all[i].col != all[i - 1].col || all[i].row != all[i - 1].row;
+            if (fresh) { P.dest.push_back({ all[i].row, all[i].col, (int)i, (int)i }); P.dest_front_ptr[all[i].front + 1]++; }
+            P.dest.back().src_end = (int)i + 1;
+            (all[i].rhs ? P.slot_rhs : P.slot_blk)[all[i].src] = (int)i;
+        }
+        for (int t = 0; t < nT; t++) P.dest_front_ptr[t + 1] += P.dest_front_ptr[t];
+        P.n_slots = (int)all.size();
+    }
+
     // ---- HBM pool offsets + statistics -----------------------------------------------------------------
     P.f_off.assign(nT, 0);
     int64_t off = 0;

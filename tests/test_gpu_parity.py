@@ -79,11 +79,12 @@ def test_tutorial_batch_mode_matches_reference_golden(lib):
     assert res[-1][0] == pytest.approx(7.805041, abs=1e-6)
 
 
-@pytest.mark.parametrize("opts", [dict(small_lds_kb=0), dict(small_lds_kb=160), dict(leaf_nodes=4), dict(leaf_nodes=40),
-                                  dict(use_graph=0), dict(device_timing=1)])
+@pytest.mark.parametrize("opts", [dict(small_lds_kb=0, medium_lds_kb=0), dict(small_lds_kb=0), dict(small_lds_kb=156),
+                                  dict(medium_lds_kb=0), dict(leaf_nodes=4), dict(leaf_nodes=40), dict(use_graph=0), dict(device_timing=1)])
 def test_every_kernel_path_agrees_with_oracle(lib, oracle, opts):
-    """force the big-front (MFMA) path, the LDS path, other leaf sizes, no hipGraph: same answers"""
-    defaults = dict(small_lds_kb=100, leaf_nodes=16, use_graph=1, device_timing=0)
+    """force the multi-workgroup big-front path, the single-workgroup L2 (medium) path, the LDS path, other
+    leaf sizes, no hipGraph: same answers"""
+    defaults = dict(small_lds_kb=100, medium_lds_kb=150, leaf_nodes=16, use_graph=1, device_timing=0)
     arr = datasets.random_pose_graph(700, 600, 21)
     oc, ost = oracle.iterate(arr, 2)
     try:
