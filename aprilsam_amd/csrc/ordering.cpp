@@ -76,6 +76,36 @@ struct HopcroftKarp {
     }
 };
 
+// unit-capacity max-flow (Dinic) used for exact vertex-separator refinement inside a band
+struct Dinic {
+    struct E { int to, cap; };
+    std::vector<E> e; std::vector<std::vector<int>> g; std::vector<int> lvl, it;
+    explicit Dinic(int n) : g(n), lvl(n), it(n) {}
+    void add(int u, int v, int c) { g[u].push_back((int)e.size()); e.push_back({ v, c }); g[v].push_back((int)e.size()); e.push_back({ u, 0 }); }
+    bool bfs(int s, int t) {
+        std::fill(lvl.begin(), lvl.end(), -1);
+        std::vector<int> q{ s }; lvl[s] = 0;
+        for (size_t h = 0; h < q.size(); h++) for (int id : g[q[h]]) if (e[id].cap > 0 && lvl[e[id].to] < 0) { lvl[e[id].to] = lvl[q[h]] + 1; q.push_back(e[id].to); }
+        return lvl[t] >= 0;
+    }
+    int dfs(int u, int t, int f) {
+        if (u == t) return f;
+        for (int &i = it[u]; i < (int)g[u].size(); i++) {
+            int id = g[u][i];
+            if (e[id].cap > 0 && lvl[e[id].to] == lvl[u] + 1) {
+                int d = dfs(e[id].to, t, std::min(f, e[id].cap));
+                if (d > 0) { e[id].cap -= d; e[id ^ 1].cap += d; return d; }
+            }
+        }
+        return 0;
+    }
+    int run(int s, int t) {
+        int flow = 0;
+        while (bfs(s, t)) { std::fill(it.begin(), it.end(), 0); while (int f = dfs(s, t, 1 << 29)) flow += f; }
+        return flow;
+    }
+};
+
 struct Dissector {
     int N;
     const std::vector<int> &ap, &ai;
@@ -138,12 +168,68 @@ struct Dissector {
             if (loc[v] == -2) { out.S.push_back(v); loc[v] = -1; }
             else if (side[v] == 0) out.P0.push_back(v); else out.P1.push_back(v);
         }
+        score(comp, out);
+    }
+
+    // cost of a split: separator size, with a steep penalty once the larger part exceeds 62 % — on the GPU
+    // the depth of the elimination tree is paid in dependent kernel launches, so balance beats a few poses
+    void score(const std::vector<int> &comp, Split &out) {
         out.ok = !out.P0.empty() && !out.P1.empty() && !out.S.empty();
         if (out.ok) {
             double n = (double)comp.size() - (double)out.S.size();
             double imb = std::max(out.P0.size(), out.P1.size()) / n;       // 0.5 .. 1
-            out.cost = (double)out.S.size() * (1.0 + 4.0 * std::max(0.0, imb - 0.6));
+            double over = std::max(0.0, imb - 0.62);
+            out.cost = (double)out.S.size() * (1.0 + 25.0 * over) + 400.0 * over * over * (double)comp.size();
         }
+    }
+
+    // Exact refinement inside a band: vertices within `width` hops of the separator are free, the rest of
+    // P0 / P1 is contracted into source / sink, and a minimum VERTEX cut of the band (node-split unit
+    // capacities, Dinic) replaces the separator.  Cleans up the ragged cuts that noisy pose positions give.
+    void refine_band(const std::vector<int> &comp, int L, Split &sp, int width) {
+        if (!sp.ok) return;
+        for (int v : sp.P0) side[v] = 0;
+        for (int v : sp.P1) side[v] = 1;
+        for (int v : sp.S) side[v] = 2;
+        std::vector<int> band;                       // BFS from the separator, depth <= width
+        for (int v : sp.S) { dist[v] = 0; band.push_back(v); }
+        for (size_t h = 0; h < band.size(); h++) {
+            int u = band[h];
+            if (dist[u] == width) continue;
+            for (int e = ap[u]; e < ap[u + 1]; e++) { int v = ai[e]; if (label[v] == L && dist[v] < 0) { dist[v] = dist[u] + 1; band.push_back(v); } }
+        }
+        const int nb = (int)band.size();
+        bool core0 = false, core1 = false;
+        for (int i = 0; i < nb; i++) loc[band[i]] = i;
+        Dinic fl(2 * nb + 2);
+        const int SRC = 2 * nb, SNK = 2 * nb + 1, INF = 1 << 28;
+        for (int i = 0; i < nb; i++) {
+            int u = band[i];
+            fl.add(2 * i, 2 * i + 1, 1);
+            bool a0 = false, a1 = false;
+            for (int e = ap[u]; e < ap[u + 1]; e++) {
+                int v = ai[e];
+                if (label[v] != L) continue;
+                if (dist[v] >= 0) fl.add(2 * i + 1, 2 * loc[v], INF);          // band -> band
+                else if (side[v] == 0) a0 = true; else a1 = true;              // neighbour in a contracted core
+            }
+            if (a0) { fl.add(SRC, 2 * i, INF); core0 = true; }
+            if (a1) { fl.add(2 * i + 1, SNK, INF); core1 = true; }
+        }
+        Split out;
+        if (core0 && core1) {
+            fl.run(SRC, SNK);
+            fl.bfs(SRC, SNK);                             // residual reachability in fl.lvl
+            for (int v : comp) {
+                if (dist[v] < 0) { (side[v] == 0 ? out.P0 : out.P1).push_back(v); continue; }
+                int i = loc[v];
+                bool rin = fl.lvl[2 * i] >= 0, rout = fl.lvl[2 * i + 1] >= 0;
+                if (rin && !rout) out.S.push_back(v); else if (rout) out.P0.push_back(v); else out.P1.push_back(v);
+            }
+            score(comp, out);
+        }
+        for (int v : band) { dist[v] = -1; loc[v] = -1; }
+        if (out.ok && out.cost < sp.cost) sp = std::move(out);
     }
 
     void split_bfs(const std::vector<int> &comp, int L, Split &out) {
@@ -171,7 +257,7 @@ struct Dissector {
         cut_to_separator(comp, L, out);
     }
 
-    void split_geometric(const std::vector<int> &comp, int L, Split &out) {
+    void split_geometric(const std::vector<int> &comp, int L, Split &out, double rot = 0.0) {
         if (!xy) { out.ok = false; return; }
         double mx = 0, my = 0; size_t n = comp.size();
         for (int v : comp) { mx += xy[2 * v]; my += xy[2 * v + 1]; }
@@ -180,7 +266,7 @@ struct Dissector {
         for (int v : comp) { double dx = xy[2 * v] - mx, dy = xy[2 * v + 1] - my; sxx += dx * dx; sxy += dx * dy; syy += dy * dy; }
         if (!(std::isfinite(sxx) && std::isfinite(syy) && std::isfinite(sxy))) { out.ok = false; return; }
         // principal direction of the 2x2 covariance
-        double th = 0.5 * std::atan2(2 * sxy, sxx - syy);
+        double th = 0.5 * std::atan2(2 * sxy, sxx - syy) + rot;
         double ux = std::cos(th), uy = std::sin(th);
         std::vector<std::pair<double, int>> pr(n);
         for (size_t i = 0; i < n; i++) { int v = comp[i]; pr[i] = { (xy[2 * v] - mx) * ux + (xy[2 * v + 1] - my) * uy, v }; }
@@ -215,12 +301,24 @@ struct Dissector {
     template <class Stack>
     void handle(std::vector<int> &comp, int L, int parent, Stack &stack) {
         if ((int)comp.size() <= leaf) { for (int v : comp) label[v] = -1; new_node(std::move(comp), parent); return; }
-        Split a, b;
-        split_geometric(comp, L, a);
-        split_bfs(comp, L, b);
-        Split *best = nullptr;
-        if (a.ok) best = &a;
-        if (b.ok && (!best || b.cost < best->cost)) best = &b;
+        Split cand[4];
+        split_geometric(comp, L, cand[0]);
+        split_geometric(comp, L, cand[1], 1.5707963267948966);          // orthogonal axis
+        split_geometric(comp, L, cand[2], 0.7853981633974483);          // diagonal
+        split_bfs(comp, L, cand[3]);
+        Split *best = nullptr, *second = nullptr;
+        for (Split &c : cand) {
+            if (!c.ok) continue;
+            if (!best || c.cost < best->cost) { second = best; best = &c; }
+            else if (!second || c.cost < second->cost) second = &c;
+        }
+        if (best && (int)comp.size() > 4 * leaf) {
+            for (Split *c : { best, second }) {
+                if (!c) continue;
+                for (int pass = 0; pass < 2; pass++) { double before = c->cost; refine_band(comp, L, *c, 2); if (c->cost >= before) break; }
+            }
+            if (second && second->cost < best->cost) best = second;
+        }
         if (!best) { for (int v : comp) label[v] = -1; new_node(std::move(comp), parent); return; }   // dense region
         for (int v : best->S) label[v] = -1;
         int t = new_node(std::move(best->S), parent);

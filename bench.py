@@ -82,6 +82,31 @@ def cpu_baseline(arrays, budget_s=12.0):
                        f"wall clock around the solver call only")
 
 
+def setup_dist(world, backend, device):
+    """One process per GPU (launched by torch.distributed.run): returns (barrier, max_over_ranks).
+    Replicas only — there is no data-path collective; the two helpers bracket the timed region and take the
+    max wall time over ranks.  `backend` is "nccl" (= RCCL) on the GPU box, "gloo" in the CPU tests."""
+    if world <= 1:
+        return (lambda: None), (lambda dt: dt)
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
+    dist.barrier()
+
+    def max_over_ranks(dt):
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return dist.barrier, max_over_ranks
+
+
+def aggregate_value(world, steps, max_dt):
+    """whole-job throughput of `world` independent replicas: GN iterations / s"""
+    return world * steps / max_dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,27 +122,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if rank == 0:
         ge.build()
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        dist.barrier()
-
-        def barrier():
-            dist.barrier()
-
-        def sync_all(dt):
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item())
-    else:
-        torch.cuda.set_device(0)
-
-        def barrier():
-            pass
-
-        def sync_all(dt):
-            return dt
+    torch.cuda.set_device(local)
+    barrier, sync_all = setup_dist(world, "nccl", torch.device("cuda", local))
     from aprilsam_amd import datasets, host
     lib = host.SolverLib()
     lib.dll.aprilsam_amd_set_device(local)
@@ -141,7 +147,7 @@ def main():
     lib.dll.aprilsam_amd_resident_sync(g.ptr, p.ptr)
     dt = timed_steps(lib, g, p, a.steps, sync_all, barrier)
     ms_per_step = 1e3 * dt / a.steps
-    value = world * a.steps / dt
+    value = aggregate_value(world, a.steps, dt)
 
     # ---- instrumented pass: same K steps, every kernel launch timed with HIP events on the solver stream ----
     lib.dll.aprilsam_amd_resident_steps(g.ptr, p.ptr, a.steps, 1)
