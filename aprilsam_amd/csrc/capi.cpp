@@ -9,6 +9,7 @@
 
 #include "../../include/aprilsam_amd.h"
 #include "plan.h"
+#include "refmodel.h"
 #include "solver.h"
 
 extern "C" {
@@ -63,6 +64,35 @@ int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, doubl
     return asam::kernel_profile(param, ms, calls, flops, bytes, names);
 }
 int aprilsam_amd_debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts) { return asam::debug_front_times(param, out, n_fronts); }
+// host logic, no GPU: the reference's elimination order (aprilsam.c:999-1249 restated) and block elimination
+// tree for a graph given as factor endpoint arrays; out_order / out_parent: n_nodes ints each
+int aprilsam_amd_reference_order(int n_nodes, int n_factors, const int *fa, const int *fb, int *out_order, int *out_parent) {
+    asam::RefModel m;
+    m.batch(n_nodes, n_factors, fa, fb);
+    memcpy(out_order, m.ord.data(), sizeof(int) * (size_t)n_nodes);
+    if (out_parent) memcpy(out_parent, m.parent.data(), sizeof(int) * (size_t)n_nodes);
+    return 0;
+}
+// test handle on the bookkeeping model (host logic only)
+void *aprilsam_amd_refmodel_create(void) { return new asam::RefModel(); }
+void aprilsam_amd_refmodel_destroy(void *m) { delete (asam::RefModel *)m; }
+void aprilsam_amd_refmodel_batch(void *m, int n_nodes, int n_factors, const int *fa, const int *fb) { ((asam::RefModel *)m)->batch(n_nodes, n_factors, fa, fb); }
+int aprilsam_amd_refmodel_inc_begin(void *m, int n_nodes, int n_factors, const int *fa, const int *fb) {
+    asam::RefModel *M = (asam::RefModel *)m;
+    M->inc_begin(n_nodes, n_factors, fa, fb);
+    return M->naffected;
+}
+// visited[i]: 0 = untouched, 1 = delta_X only, 2 = updated.  Returns start_over after the traversal.
+int aprilsam_amd_refmodel_solve_visit(void *m, const double *x, double dxy, double dth, int *visited) {
+    asam::RefModel *M = (asam::RefModel *)m;
+    for (int i = 0; i < M->N; i++) visited[i] = 0;
+    M->solve_visit(x, dxy, dth, [&](int n, bool upd) { visited[n] = upd ? 2 : 1; });
+    return M->start_over;
+}
+void aprilsam_amd_refmodel_get(void *m, int *parent, int *changed, int *relin) {
+    asam::RefModel *M = (asam::RefModel *)m;
+    for (int i = 0; i < M->N; i++) { if (parent) parent[i] = M->parent[i]; if (changed) changed[i] = M->changed[i]; if (relin) relin[i] = M->relin[i]; }
+}
 const char *aprilsam_amd_version(void) { return "aprilsam_amd 0.1 (gfx950, multifrontal FP64)"; }
 void aprilsam_amd_free(void *p) { free(p); }
 

@@ -1,0 +1,224 @@
+// refmodel.cpp — host-side model of the reference's BOOKKEEPING for the incremental path.
+//
+// Measured on this build's oracle (tools/inc_experiment in DESIGN.md §7): on the poses it touches, the
+// reference's incremental result equals the exact solution of the incremental linear system to 1e-12.
+// What makes april_graph_cholesky_inc differ from "solve and update everything" is bookkeeping only:
+//   * which poses are visited / updated by solve_node (aprilsam.c:721-779): all of them when more than 5
+//     tree nodes are affected, otherwise the marked root paths plus their direct children (x computed,
+//     delta_X overwritten, not updated);
+//   * the relinearisation counter start_over (aprilsam.c:741-751) that triggers the batch fall-back (:566).
+// Both are functions of the reference's block elimination tree (aprilsam.c:613-657, 908-987), i.e. of ITS
+// elimination order (aprilsam.c:999-1249) extended by identity for new poses (:393-396).  This file restates
+// that order (including the quirks that decide ties) and the tree as pure integer logic; the numbers come
+// from the GPU.  Nothing here touches floating-point data except the threshold tests on x.
+#include "refmodel.h"
+
+#include <algorithm>
+#include <cmath>
+#include <deque>
+#include <unordered_map>
+
+namespace asam {
+
+namespace {
+
+// binary max-heap with the sift rules of common/zmaxheap.c:134-159 (add: climb while parent < v) and
+// :181-241 (remove root: last element to the top, descend towards the larger child, left on ties)
+struct RefHeap {
+    std::vector<float> val; std::vector<int> item;
+    void add(int it, float v) {
+        int idx = (int)val.size();
+        val.push_back(v); item.push_back(it);
+        while (idx > 0) {
+            int parent = (idx - 1) / 2;
+            if (val[parent] >= v) break;
+            std::swap(val[idx], val[parent]); std::swap(item[idx], item[parent]);
+            idx = parent;
+        }
+    }
+    bool pop(int *it, float *v) {
+        if (val.empty()) return false;
+        *it = item[0]; *v = val[0];
+        int n = (int)val.size() - 1;
+        if (n == 0) { val.clear(); item.clear(); return true; }
+        val[0] = val[n]; item[0] = item[n];
+        val.pop_back(); item.pop_back();
+        int parent = 0;
+        const float ps = val[0];
+        while (parent < n) {
+            int left = 2 * parent + 1, right = left + 1;
+            float ls = left < n ? val[left] : -INFINITY, rs = right < n ? val[right] : -INFINITY;
+            if (ps >= ls && ps >= rs) break;
+            int ch = (ls >= rs) ? left : right;
+            std::swap(val[parent], val[ch]); std::swap(item[parent], item[ch]);
+            parent = ch;
+        }
+        return true;
+    }
+};
+
+}  // namespace
+
+// aprilsam.c:999-1249 restated.  adj: sorted neighbour lists without self loops (the rows of the symbolic
+// matrix built at aprilsam.c:104-114).  Returns position -> node.
+std::vector<int> ref_min_degree_order(int N, const std::vector<std::vector<int>> &adj) {
+    std::vector<std::vector<int>> nb(adj);
+    std::vector<std::deque<int>> lists;
+    std::unordered_map<uint32_t, int> registry;          // key -> list (only lists created with a hash put)
+    RefHeap heap;
+    auto add_registered = [&](uint32_t key, int node) {
+        auto it = registry.find(key);
+        if (it != registry.end()) { lists[it->second].push_back(node); return; }
+        lists.emplace_back(); lists.back().push_back(node);
+        registry[key] = (int)lists.size() - 1;
+        heap.add((int)lists.size() - 1, (float)(-1.0 * key));
+    };
+    std::vector<char> set_marker(N, 0);
+    if (N > 0) {
+        // "most recent node set the lowest score" (:1021-1098)
+        const int rowi = N - 1;
+        add_registered((uint32_t)(nb[rowi].size() + 2 * rowi), rowi);
+        set_marker[rowi] = 1;
+        for (size_t i = 0; i < nb[rowi].size(); i++) {
+            const int choose = nb[rowi][i];
+            for (int idx = choose - 5; idx < choose + 5; idx++) {
+                if (idx < 0 || idx > N - 1) continue;
+                if (set_marker[idx]) continue;
+                add_registered((uint32_t)(nb[idx].size() + rowi), idx);
+                set_marker[idx] = 1;
+                // :1080-1095 — the loop variable itself is used as a node id and is never marked
+                for (int j = 0; j < (int)nb[idx].size(); j++) {
+                    if (set_marker[j]) continue;
+                    add_registered((uint32_t)(nb[j].size() + rowi), j);
+                }
+            }
+        }
+    }
+    for (int rowi = 0; rowi < N - 1; rowi++) {           // :1100-1116
+        if (set_marker[rowi]) continue;
+        add_registered((uint32_t)nb[rowi].size(), rowi);
+    }
+    std::vector<int> ordering; ordering.reserve(N);
+    std::vector<char> gone(N, 0);
+    std::vector<int> setm(N, 0); int token = 0;
+    int li; float v;
+    while (heap.pop(&li, &v)) {                           // :1128-1238
+        while (!lists[li].empty()) {
+            const int b = lists[li].front(); lists[li].pop_front();
+            if (gone[b]) continue;
+            if ((float)nb[b].size() <= -v) {
+                ordering.push_back(b); gone[b] = 1;
+                for (size_t ai = 0; ai < nb[b].size(); ai++) {          // its neighbours become a clique
+                    const int a = nb[b][ai];
+                    std::vector<int> &na = nb[a];
+                    token++;
+                    for (size_t i = 0; i < na.size(); i++) {
+                        if (na[i] == b) { na[i] = na.back(); na.pop_back(); i--; continue; }
+                        setm[na[i]] = token;
+                    }
+                    setm[b] = token; setm[a] = token;
+                    for (size_t bi = 0; bi < nb[b].size(); bi++) { const int c = nb[b][bi]; if (setm[c] != token) na.push_back(c); }
+                }
+            } else {                                                    // :1224-1235 (no hash put for a new list)
+                const uint32_t key = (uint32_t)nb[b].size();
+                auto it = registry.find(key);
+                if (it != registry.end()) lists[it->second].push_back(b);
+                else { lists.emplace_back(); lists.back().push_back(b); heap.add((int)lists.size() - 1, (float)(-1.0 * key)); }
+            }
+        }
+    }
+    return ordering;
+}
+
+// block elimination tree under `ord` (position -> node): parent[c] = node owning the first off-diagonal block of
+// c's row in U (aprilsam.c:635-651) = Liu's elimination tree of the pose graph, -1 when the row has none
+static void block_etree(int N, const std::vector<std::vector<int>> &adj, const std::vector<int> &ord, const std::vector<int> &pos,
+                        std::vector<int> &parent) {
+    parent.assign(N, -1);
+    std::vector<int> anc(N, -1);               // by position
+    std::vector<int> ppos(N, -1);
+    for (int p = 0; p < N; p++) {
+        const int v = ord[p];
+        for (int w : adj[v]) {
+            int q = pos[w];
+            if (q >= p) continue;
+            while (q != -1 && q < p) {
+                int next = anc[q];
+                anc[q] = p;
+                if (next == -1) ppos[q] = p;
+                q = next;
+            }
+        }
+    }
+    for (int p = 0; p < N; p++) parent[ord[p]] = ppos[p] >= 0 ? ord[ppos[p]] : -1;
+}
+
+void RefModel::add_factor_edges(int a, int b) {
+    if (b < 0 || a == b) return;
+    auto ins = [&](int u, int w) { auto &L = adj[u]; auto it = std::lower_bound(L.begin(), L.end(), w); if (it == L.end() || *it != w) L.insert(it, w); };
+    ins(a, b); ins(b, a);
+}
+
+// after a batch step on the first n_nodes nodes / n_factors factors (aprilsam.c:121,269)
+void RefModel::batch(int n_nodes, int n_factors, const int *fa, const int *fb) {
+    N = n_nodes; F = n_factors;
+    adj.assign(N, {});
+    for (int f = 0; f < F; f++) add_factor_edges(fa[f], fb[f]);
+    ord = ref_min_degree_order(N, adj);
+    pos.assign(N, -1);
+    for (int p = 0; p < N; p++) pos[ord[p]] = p;
+    block_etree(N, adj, ord, pos, parent);
+    changed.assign(N, 0); relin.assign(N, 0);
+    start_over = 0; naffected = 0;
+    root = N > 0 ? ord[N - 1] : -1;
+    valid = true;
+}
+
+// aprilsam.c:393-498 + 550: extend the order by identity, mark the root paths of the new factors' poses in
+// the OLD tree, then re-parent (the structure of U after the partial re-factorisation)
+void RefModel::inc_begin(int n_nodes, int n_factors, const int *fa, const int *fb) {
+    const int oldN = N;
+    adj.resize(n_nodes); parent.resize(n_nodes, -1); changed.resize(n_nodes, 0); relin.resize(n_nodes, 0);
+    for (int i = oldN; i < n_nodes; i++) { ord.push_back(i); pos.push_back(i); }
+    naffected = 0;
+    for (int f = F; f < n_factors; f++) {
+        const int nodes[2] = { fa[f], fb[f] };
+        for (int z0 = 0; z0 < (fb[f] >= 0 ? 2 : 1); z0++) {
+            int n = nodes[z0];
+            while (!changed[n]) {
+                changed[n] = 1; naffected++;
+                if (parent[n] != -1) n = parent[n]; else break;
+            }
+        }
+    }
+    for (int f = F; f < n_factors; f++) add_factor_edges(fa[f], fb[f]);
+    N = n_nodes; F = n_factors;
+    block_etree(N, adj, ord, pos, parent);
+    root = ord[N - 1];
+}
+
+// aprilsam.c:721-779.  x: 3 doubles per node (node order).  visit(node, update) is called for every pose the
+// reference touches: update == true -> node->update(x) (state, delta_X); false -> only delta_X = x.
+void RefModel::solve_visit(const double *x, double dxy, double dth, const std::function<void(int, bool)> &visit) {
+    std::vector<int> cptr(N + 1, 0), cidx(N);
+    for (int i = 0; i < N; i++) if (parent[i] >= 0) cptr[parent[i] + 1]++;
+    for (int i = 0; i < N; i++) cptr[i + 1] += cptr[i];
+    { std::vector<int> fill(cptr.begin(), cptr.end() - 1); for (int i = 0; i < N; i++) if (parent[i] >= 0) cidx[fill[parent[i]]++] = i; }
+    std::vector<int> stack; stack.push_back(root);
+    while (!stack.empty()) {
+        const int n = stack.back(); stack.pop_back();
+        const double *xi = x + 3 * (size_t)n;
+        if (std::fabs(xi[0]) > dxy || std::fabs(xi[1]) > dxy || std::fabs(xi[2]) > dth) {
+            if (!relin[n]) { relin[n] = 1; start_over++; }
+        }
+        bool update = true;
+        if (naffected > 5) changed[n] = 0;
+        else if (changed[n] == 1) changed[n] = 0;
+        else update = false;
+        visit(n, update);
+        if (!update) continue;                       // :769 returns before the children
+        for (int k = cptr[n]; k < cptr[n + 1]; k++) stack.push_back(cidx[k]);
+    }
+}
+
+}  // namespace asam

@@ -1,0 +1,27 @@
+// refmodel.h — host-side model of the reference's incremental bookkeeping (see refmodel.cpp)
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <vector>
+
+namespace asam {
+
+std::vector<int> ref_min_degree_order(int N, const std::vector<std::vector<int>> &adj);
+
+struct RefModel {
+    bool valid = false;
+    int N = 0, F = 0;
+    std::vector<std::vector<int>> adj;      // pose adjacency, sorted, no self loops
+    std::vector<int> ord, pos;              // position -> node, node -> position (reference order, identity-extended)
+    std::vector<int> parent;                // block elimination tree, node -> parent node or -1
+    std::vector<unsigned char> changed;     // label_changed
+    std::vector<unsigned char> relin;       // label_relinearized
+    int start_over = 0, naffected = 0, root = -1;
+
+    void add_factor_edges(int a, int b);
+    void batch(int n_nodes, int n_factors, const int *fa, const int *fb);
+    void inc_begin(int n_nodes, int n_factors, const int *fa, const int *fb);
+    void solve_visit(const double *x, double dxy, double dth, const std::function<void(int, bool)> &visit);
+};
+
+}  // namespace asam

@@ -21,6 +21,7 @@
 #include "../../include/aprilsam_amd.h"
 #include "kernels.hip.h"
 #include "plan.h"
+#include "refmodel.h"
 #include "solver.h"
 
 namespace asam {
@@ -120,6 +121,7 @@ struct GraphPack {
     DBuf<int> d_fa, d_fb;
     DBuf<double> d_z, d_W, d_state, d_lp, d_dx, d_chi2f, d_scalar;
     int F_on_device = 0;               // factors already uploaded
+    int F_cap = 0;                     // device capacity (factors) of d_fa/d_fb/d_z/d_W/d_chi2f
     hipStream_t stream = nullptr;
     HBuf<double> h_scalar;
     void release() {
@@ -182,8 +184,10 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g) {
 }
 static void upload_factors(GraphPack &gp) {
     const int F = gp.F;
-    if (F > (int)gp.d_fa.cap) {   // reallocation loses the old content: re-upload everything
-        gp.d_fa.need(F); gp.d_fb.need(F); gp.d_z.need((size_t)3 * F); gp.d_W.need((size_t)9 * F);
+    if (F > gp.F_cap) {           // reallocation loses the old content: re-upload everything
+        gp.F_cap = std::max(F, gp.F_cap + gp.F_cap / 2 + 64);
+        gp.d_fa.need(gp.F_cap); gp.d_fb.need(gp.F_cap); gp.d_z.need((size_t)3 * gp.F_cap); gp.d_W.need((size_t)9 * gp.F_cap);
+        gp.d_chi2f.need(gp.F_cap);
         gp.F_on_device = 0;
     }
     const int f0 = gp.F_on_device;
@@ -195,7 +199,7 @@ static void upload_factors(GraphPack &gp) {
         HIPCHECK(hipMemcpyAsync(gp.d_W.p + (size_t)9 * f0, gp.h_W.p + (size_t)9 * f0, n * 72, hipMemcpyHostToDevice, gp.stream));
     }
     gp.F_on_device = F;
-    gp.d_chi2f.need(F); gp.d_scalar.need(8); gp.h_scalar.need(8);
+    gp.d_scalar.need(8); gp.h_scalar.need(8);
 }
 // states (and l_points) of all nodes -> pinned host -> device
 static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp) {
@@ -257,8 +261,8 @@ struct Context {
     // incremental bookkeeping (aprilsam.c:741-751, 566-575)
     bool have_fact = false;               // a batch factorisation exists (reference: param->chol != NULL)
     int batch_nodes = 0;                  // #nodes at the last batch step (those carry the Tikhonov term)
-    std::vector<unsigned char> relin;     // label_relinearized per node since the last batch
-    int start_over = 0;
+    RefModel model;                       // the reference's tree / counters (refmodel.cpp), rebuilt lazily after a batch
+    int batch_factors = 0;                // #factors at the last batch step
     // captured numeric phase
     hipGraphExec_t gexec = nullptr;
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
@@ -589,7 +593,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
         param->nreordering = N;
         param->factor_num = F;
-        c.have_fact = true; c.batch_nodes = N; c.relin.assign(N, 0); c.start_over = 0;
+        c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = false;
         if (param->delta_x) {                                                // aprilsam.c:363-366
             free(param->delta_x);
             param->delta_x = (double *)calloc((size_t)3 * N, sizeof(double));
@@ -622,12 +626,12 @@ void batch_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// incremental step (aprilsam.c:377-576).  Round-1 semantics: the linear system the reference maintains
-// by partial un-/re-factorisation — every factor linearised at its nodes' l_point (aprilsam.c:508-542;
-// l_points only move in a batch step), Tikhonov term only on nodes present at the last batch step
-// (aprilsam.c:197-204 vs :508-542) — is re-assembled and re-factorised in full on the GPU, and ALL nodes
-// are updated (the reference's behaviour when naffected > 5, aprilsam.c:755-756).  The relinearisation
-// counter and the batch fall-back (aprilsam.c:741-751, 566-575) follow the reference.
+// incremental step (aprilsam.c:377-576).  The linear system the reference maintains by partial un-/re-
+// factorisation — every factor linearised at its nodes' l_point (aprilsam.c:508-542; l_points only move in
+// a batch step), Tikhonov term only on poses present at the last batch step (aprilsam.c:197-204 vs :508-542)
+// — is solved on the GPU (round 1: re-assembled and re-factorised in full); WHICH poses receive the result,
+// the relinearisation counter and the batch fall-back follow the reference exactly through the bookkeeping
+// model of refmodel.cpp (measured: on the poses it touches, the reference's result is the exact solution).
 // ------------------------------------------------------------------------------------------------------
 void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0) return;          // aprilsam.c:380-381
@@ -644,6 +648,8 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     pack_factors(gp, g);
     pack_states(gp, g, true);
     const int N = gp.N, F = gp.F;
+    if (!c.model.valid) c.model.batch(c.batch_nodes, c.batch_factors, gp.h_fa.p, gp.h_fb.p);      // lazily, after a batch step
+    c.model.inc_begin(N, F, gp.h_fa.p, gp.h_fb.p);
     const bool reused = prepare_plan(c, gp, g);
     upload_factors(gp);
     c.h_lambda.assign(N, 0.0);
@@ -661,18 +667,18 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
         if (!warned) { fprintf(stderr, "aprilsam_amd: incremental system not positive definite; node states left untouched\n"); warned = true; }
         return;
     }
+    // bookkeeping exactly as the reference: which poses solve_node visits / updates, start_over (refmodel.cpp)
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
-    c.relin.resize(N, 0);
-    const double dxy = param->delta_xy, dth = param->delta_theta;
-    for (int i = 0; i < N; i++) {
-        april_graph_node_t *n = ns[i];
-        n->UID = i;                                                       // aprilsam.c:474
-        const double *dx = gp.h_dx.p + (size_t)3 * i;
-        if (std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2])) continue;
-        if ((fabs(dx[0]) > dxy || fabs(dx[1]) > dxy || fabs(dx[2]) > dth) && !c.relin[i]) { c.relin[i] = 1; c.start_over++; }   // aprilsam.c:742-747
-        memcpy(n->state, gp.h_state.p + (size_t)3 * i, 24);
-        memcpy(n->delta_X, dx, 24);
-    }
+    for (int i = 0; i < N; i++) ns[i]->UID = i;                          // aprilsam.c:474
+    const double *x = gp.h_dx.p;                                          // dx per node; NaN where the solve produced NaN
+    c.model.solve_visit(x, param->delta_xy, param->delta_theta, [&](int n, bool update) {
+        april_graph_node_t *nd = ns[n];
+        const double *dx = x + (size_t)3 * n;
+        memcpy(nd->delta_X, dx, 24);                                      // aprilsam.c:752-754
+        if (!update) return;
+        if (std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2])) return;   // april_graph_xyt.c:304-305
+        memcpy(nd->state, gp.h_state.p + (size_t)3 * n, 24);              // l_point + dx, theta wrapped (k_update_states)
+    });
     if (param->ordering) free(param->ordering);
     param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
     memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
@@ -680,8 +686,8 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     param->factor_num = F;
     const double step_ms = now_ms() - t0;
     c.st.ms_total = step_ms;
-    if (!g_opt.deterministic && step_ms > param->batch_time / 3) c.start_over = 0x7fffffff;       // aprilsam.c:557-559
-    if (c.start_over > param->nthreshold) {                                                      // aprilsam.c:566-575
+    if (!g_opt.deterministic && step_ms > param->batch_time / 3) c.model.start_over = 0x7fffffff;    // aprilsam.c:557-559
+    if (c.model.start_over > param->nthreshold) {                                                   // aprilsam.c:566-575
         const double b0 = now_ms();
         batch_impl(g, param);
         param->batch_time = now_ms() - b0;
@@ -814,7 +820,7 @@ int resident_end(april_graph_t *g, april_graph_cholesky_param_t *param) {
     param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
     memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
     param->nreordering = N; param->factor_num = F;
-    c.have_fact = true; c.batch_nodes = N; c.relin.assign(N, 0); c.start_over = 0;
+    c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = false;
     return 0;
 }
 int batch_resident(april_graph_t *g, april_graph_cholesky_param_t *param, int iters, double *chi2_out, double *ms_out) {

@@ -235,6 +235,19 @@ void aprilsam_amd_plan_destroy(aprilsam_amd_plan_t *plan);
 long long aprilsam_amd_plan_query(const aprilsam_amd_plan_t *plan, const char *what, long long **out);
 void aprilsam_amd_free(void *p);
 
+/* Host logic behind the incremental path: the reference's elimination order (aprilsam.c:999-1249, restated
+ * with its tie-breaking) and the block elimination tree it implies (aprilsam.c:613-657).  fb[i] < 0 marks a
+ * unary factor.  out_order: position -> node; out_parent (may be NULL): node -> parent node or -1. */
+int aprilsam_amd_reference_order(int n_nodes, int n_factors, const int *fa, const int *fb, int *out_order, int *out_parent);
+
+/* test handle on the same bookkeeping model, stepped explicitly (see tests/test_refmodel.py) */
+void *aprilsam_amd_refmodel_create(void);
+void  aprilsam_amd_refmodel_destroy(void *m);
+void  aprilsam_amd_refmodel_batch(void *m, int n_nodes, int n_factors, const int *fa, const int *fb);
+int   aprilsam_amd_refmodel_inc_begin(void *m, int n_nodes, int n_factors, const int *fa, const int *fb);   /* -> naffected */
+int   aprilsam_amd_refmodel_solve_visit(void *m, const double *x, double dxy, double dth, int *visited);    /* -> start_over */
+void  aprilsam_amd_refmodel_get(void *m, int *parent, int *changed, int *relin);
+
 /* ---- synthetic Manhattan lattice generator ----------------------- */
 /* Appends K*K xyt nodes, the in-bounds 4-direction xyt factors and the node-0 prior to `graph`.
  * Returns the number of factors added. */

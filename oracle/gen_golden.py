@@ -96,6 +96,14 @@ def main():
                             **{f"states_{i}": s for i, (_, s) in enumerate(res)})
         print("tutorial", name, [round(c, 6) for c, _ in res])
 
+    # 4b. incremental demo (examples/aprilsam_demo.c semantics), deterministic schedule: the wall-clock rule
+    #     aprilsam.c:557 is neutralised by setting param->batch_time = 1e300 before every incremental call
+    res = harness.run_demo(ref, (st, fa, fb, z, W), deterministic=True)
+    np.savez_compressed(os.path.join(GOLD, "m3500_inc_demo.npz"), chi2=res["chi2"], was_batch=res["was_batch"],
+                        final_states=res["final_states"], ref_ms=res["ms"])
+    print("inc demo: final chi2", res["chi2"][-1], "fallbacks", int(res["was_batch"].sum()) - 1,
+          "at node counts", (np.nonzero(res["was_batch"])[0] + 1)[:8], "total ms", res["ms"].sum())
+
     # 5. lattices
     for K, iters in ((6, 4), (24, 4), (60, 3)) + (((120, 2),) if a.big else ()):
         out = batch_trace(ref, prod.lattice_arrays(K), iters)

@@ -123,3 +123,12 @@ void rs_build_from_arrays(april_graph_t *g, int N, const double *states, int F, 
     }
     matd_destroy(Wm);
 }
+
+/* search tree introspection (aprilsam.h:190-219) for the tests of the bookkeeping model */
+int  rs_tree_nnodes(april_graph_cholesky_param_t *p) { return p->tr ? p->tr->nnodes : 0; }
+void rs_tree_parents(april_graph_cholesky_param_t *p, int *out) { for (int i = 0; i < p->tr->nnodes; i++) out[i] = p->tr->nodes[i].parent; }
+void rs_tree_labels(april_graph_cholesky_param_t *p, int *changed, int *relin)
+{
+    for (int i = 0; i < p->tr->nnodes; i++) { changed[i] = p->tr->nodes[i].label_changed; relin[i] = p->tr->nodes[i].label_relinearized; }
+}
+int  rs_tree_root(april_graph_cholesky_param_t *p) { return (int)(p->tr->root - p->tr->nodes); }

@@ -49,7 +49,7 @@ def case(name, arr, iters=1, opts=None, tol=1e-6):
         return False
     finally:
         for k in opts:
-            lib.set_option(k, {"small_lds_kb": 100, "medium_lds_kb": 150, "leaf_nodes": 16, "use_graph": 1}[k])
+            lib.set_option(k, {"small_lds_kb": 156, "medium_lds_kb": 0, "leaf_nodes": 16, "use_graph": 1}[k])
 
 
 quick = "--quick" in sys.argv
