@@ -57,7 +57,7 @@ struct Plan {
     std::vector<int> rd_src;          // contribution id = 2*factor + {0: g_a, 1: g_b}
     std::vector<uint8_t> fac_swap;    // 1 if the off-diagonal block must be stored transposed (la < lb)
     // the same lists flattened for the device: one record per destination block of a front, sorted by
-    // (front, block col, block row) with the rhs row as block row nbc; contributions are stored by the
+    // (front, block col, block row) with brow = -1 for the rhs row; contributions are stored by the
     // linearise kernel in SLOT order (= destination order), so a front's inputs are one contiguous stream.
     struct DestRec { int brow, bcol, src_begin, src_end; };
     std::vector<int> dest_front_ptr;  // per front: range of DestRec, size nF+1

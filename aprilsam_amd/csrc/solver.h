@@ -11,6 +11,7 @@ struct Options {
     int device_timing = 0;        // record HIP events per stage (disables graph replay for that call)
     int trust_factor_cache = 1;   // z/W of factors already packed are treated as immutable
     int small_lds_kb = 156;       // fronts whose LDS image fits run in the single-workgroup LDS kernel
+    int inc_fast = 1;             // incremental steps regenerate only the dirty root paths (0: full re-plan per step)
     int medium_lds_kb = 0;        // fronts whose 32-column panel fits run in the single-workgroup L2 kernel (0 = off)
 };
 extern Options g_opt;

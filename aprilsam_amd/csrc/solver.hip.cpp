@@ -61,6 +61,7 @@ static void load_env_options() {
         v = g_opt.trust_factor_cache; envd("APRILSAM_AMD_TRUST_FACTOR_CACHE", &v); g_opt.trust_factor_cache = (int)v;
         v = g_opt.small_lds_kb; envd("APRILSAM_AMD_SMALL_LDS_KB", &v); g_opt.small_lds_kb = (int)v;
         v = g_opt.medium_lds_kb; envd("APRILSAM_AMD_MEDIUM_LDS_KB", &v); g_opt.medium_lds_kb = (int)v;
+        v = g_opt.inc_fast; envd("APRILSAM_AMD_INC_FAST", &v); g_opt.inc_fast = (int)v;
     });
 }
 
@@ -234,6 +235,27 @@ struct LevelPlan {
     int all_off = 0, n_all = 0; size_t solve_lds = 0;          // every front (k_backsolve)
 };
 
+// state of the incremental fast path (inc_fast.*): the plan of the last batch step stays frozen, poses added since
+// form one growing TAIL front at the root, and only fronts on the root paths of changed leaves are regenerated
+struct IncState {
+    bool ready = false;                     // helper tables below are built for the current base plan
+    int Nb = 0, Fb = 0, nF0 = 0, nLev0 = 0;
+    long long i32_used = 0, dest_used = 0, child_used = 0, tab_used = 0, pool_used = 0, pool_cap = 0, o_rows = 0, o_rel = 0;
+    int slots_used = 0;
+    std::vector<FrontDesc> fd;              // host mirror of the device descriptors (base fronts, then TAIL)
+    std::vector<int> pos_front;             // base position -> base front
+    std::vector<int> parent;                // current assembly parent (base roots get TAIL once they see tail rows)
+    std::vector<std::vector<int>> E;        // per base front: tail nodes in its extended struct (sorted)
+    std::vector<std::vector<int>> xfac;     // per front (TAIL = index nF0): factors added since the batch
+    std::vector<int> bf_ptr, bf_idx;        // base factors owned by each base front (CSR)
+    std::vector<int> rel_begin;             // per front: absolute offset of its current child->parent block map
+    std::vector<int> cur_nub;               // per front: current update blocks
+    std::vector<long long> cur_cap;         // per front: doubles allocated at fd.off
+    std::vector<char> dirty;
+    std::vector<int> f_level;               // base levels, TAIL = nLev0
+    std::vector<LevelPlan> base_levels;     // launch tables of all fronts per level for the back substitution
+};
+
 struct Context {
     Plan plan;
     bool have_plan = false;
@@ -261,6 +283,9 @@ struct Context {
     // incremental bookkeeping (aprilsam.c:741-751, 566-575)
     bool have_fact = false;               // a batch factorisation exists (reference: param->chol != NULL)
     int batch_nodes = 0;                  // #nodes at the last batch step (those carry the Tikhonov term)
+    IncState inc;
+    int inc_F = 0, inc_N = 0;                      // factors / nodes folded into the factorisation so far
+    std::vector<int> inc_slot_blk, inc_slot_rhs;   // slots of the factors added since the base plan (3 / 2 per factor)
     RefModel model;                       // the reference's tree / counters (refmodel.cpp), rebuilt lazily after a batch
     int batch_factors = 0;                // #factors at the last batch step
     // captured numeric phase
@@ -297,12 +322,65 @@ bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out)
     return true;
 }
 
+// slack reserved at plan upload so that the incremental path can append without reallocating device buffers
+constexpr int INC_NODES = 4096, INC_FACT = 16384, INC_I32 = 4 << 20, INC_DEST = 1 << 20, INC_CHILD = 1 << 18, INC_TAB = 1 << 20;
+constexpr long long INC_POOL_MIN = 64ll << 20;            // doubles (512 MB)
+
+// classify the fronts of one level (small / medium / big) and append their launch tables to `tab`
+template <class Dims>
+static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int> &tab, Dims dims) {
+    const size_t small_max = (size_t)g_opt.small_lds_kb * 1024, med_max = (size_t)g_opt.medium_lds_kb * 1024;
+    L = LevelPlan();
+    std::vector<int> small, med, big;
+    size_t maxm = 0;
+    auto rows = [&](int t) { int a, b; dims(t, &a, &b); return 3 * (a + b + 1); };
+    auto cols = [&](int t) { int a, b; dims(t, &a, &b); return 3 * (a + b); };
+    auto nsb_of = [&](int t) { int a, b; dims(t, &a, &b); return a; };
+    for (int t : fronts) {
+        const int R = rows(t), C = cols(t);
+        maxm = std::max<size_t>(maxm, C);
+        const size_t lds_s = small_front_lds(R, C), lds_m = medium_front_lds(R);
+        if (lds_s <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); }
+        else if (lds_m <= med_max) { med.push_back(t); L.med_lds = std::max(L.med_lds, lds_m); }
+        else { big.push_back(t); L.asm_lds = std::max(L.asm_lds, scratch_bytes(R)); }
+    }
+    // longest-processing-time first: the widest fronts of a level start first
+    std::sort(small.begin(), small.end(), [&](int a, int b) { int ra = rows(a), rb = rows(b); return ra != rb ? ra > rb : a < b; });
+    L.all_off = (int)tab.size(); L.n_all = (int)fronts.size();
+    tab.insert(tab.end(), fronts.begin(), fronts.end());
+    L.solve_lds = (maxm + NB + 8) * 8;
+    L.small_off = (int)tab.size(); L.n_small = (int)small.size();
+    tab.insert(tab.end(), small.begin(), small.end());
+    L.med_off = (int)tab.size(); L.n_med = (int)med.size();
+    tab.insert(tab.end(), med.begin(), med.end());
+    L.n_big = (int)big.size();
+    if (big.empty()) return;
+    std::sort(big.begin(), big.end(), [&](int a, int b) { return nsb_of(a) != nsb_of(b) ? nsb_of(a) > nsb_of(b) : a < b; });
+    int list_off = (int)tab.size();
+    tab.insert(tab.end(), big.begin(), big.end());
+    auto make = [&](int nact, auto count) {
+        Launch La; La.list_off = list_off; La.n = nact; La.pre_off = (int)tab.size();
+        int acc = 0; tab.push_back(0);
+        for (int i = 0; i < nact; i++) { acc += count(big[i]); tab.push_back(acc); }
+        La.grid = acc;
+        return La;
+    };
+    L.asm_big = make((int)big.size(), [&](int t) { return asm_chunks(cols(t) / 3); });
+    int steps = (3 * nsb_of(big[0]) + NB - 1) / NB;
+    for (int sidx = 0; sidx < steps; sidx++) {
+        int nact = 0;
+        while (nact < (int)big.size() && 3 * nsb_of(big[nact]) > sidx * NB) nact++;
+        L.panel.push_back(make(nact, [&](int t) { return panel_tiles(rows(t), 3 * nsb_of(t), sidx); }));
+        L.syrk.push_back(make(nact, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), sidx); }));
+    }
+}
+
 // upload the symbolic plan and build the per-level launch tables
 static void upload_plan(Context &c, hipStream_t s) {
     const Plan &P = c.plan;
     if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
     // ---- descriptors + index arrays ----------------------------------------------------------------------------
-    std::vector<FrontDesc> fd(P.nF);
+    std::vector<FrontDesc> &fd = c.inc.fd; fd.assign(P.nF, FrontDesc());
     std::vector<ChildRec> ch(std::max<size_t>(1, P.ch_idx.size()));
     for (int t = 0; t < P.nF; t++) {
         FrontDesc &d = fd[t];
@@ -310,88 +388,62 @@ static void upload_plan(Context &c, hipStream_t s) {
         d.off = P.f_off[t]; d.nsb = P.f_nsb[t]; d.nub = P.f_nub[t]; d.first = P.f_first[t];
         d.dest_begin = P.dest_front_ptr[t]; d.dest_end = P.dest_front_ptr[t + 1];
         d.ch_begin = P.ch_ptr[t]; d.ch_end = P.ch_ptr[t + 1];
-        d.rows_begin = (int)P.f_rows_ptr[t]; d.parent = P.f_parent[t];
+        d.rows_begin = 0; d.parent = P.f_parent[t];      // rows_begin patched below (absolute offset in the int arena)
     }
     for (size_t k = 0; k < P.ch_idx.size(); k++) {
         const int cfr = P.ch_idx[k];
         ChildRec &r = ch[k];
         r.cR = P.rows(cfr); r.cnu = P.f_nub[cfr];
         r.uoff = P.f_off[cfr] + (long long)(3 * P.f_nsb[cfr]) * r.cR + 3 * P.f_nsb[cfr];
-        r.rel_begin = (int)P.f_rows_ptr[cfr]; r.pad = 0;
+        r.rel_begin = 0; r.pad = cfr;                  // rel_begin patched below; pad keeps the child's front id
     }
     std::vector<int> i32;
     auto put32 = [&](const std::vector<int> &v) { size_t o = i32.size(); i32.insert(i32.end(), v.begin(), v.end()); if (v.empty()) i32.push_back(0); return o; };
-    size_t o_rows = put32(P.f_rows), o_rel = put32(P.f_rel), o_sb = put32(P.slot_blk), o_sr = put32(P.slot_rhs);
-    c.d_i32.need(i32.size()); c.d_fd.need(fd.size()); c.d_child.need(ch.size()); c.d_dest.need(std::max<size_t>(1, P.dest.size()));
+    size_t o_rows = put32(P.f_rows), o_rel = put32(P.f_rel);
+    size_t o_sb = put32(P.slot_blk); i32.resize(i32.size() + (size_t)3 * INC_FACT, -1);      // room for factors added incrementally
+    size_t o_sr = put32(P.slot_rhs); i32.resize(i32.size() + (size_t)2 * INC_FACT, -1);
+    c.inc.i32_used = (long long)i32.size(); c.inc.dest_used = (long long)P.dest.size(); c.inc.child_used = (long long)P.ch_idx.size();
+    for (int t = 0; t < P.nF; t++) fd[t].rows_begin = (int)(o_rows + P.f_rows_ptr[t]);
+    for (size_t k = 0; k < P.ch_idx.size(); k++) ch[k].rel_begin = (int)(o_rel + P.f_rows_ptr[ch[k].pad]);
+    c.d_i32.need(i32.size() + INC_I32); c.d_fd.need(fd.size() + 1); c.d_child.need(ch.size() + INC_CHILD);
+    c.d_dest.need(std::max<size_t>(1, P.dest.size()) + INC_DEST);
     HIPCHECK(hipMemcpyAsync(c.d_i32.p, i32.data(), i32.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_fd.p, fd.data(), fd.size() * sizeof(FrontDesc), hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_child.p, ch.data(), ch.size() * sizeof(ChildRec), hipMemcpyHostToDevice, s));
     static_assert(sizeof(DestRec) == sizeof(Plan::DestRec), "DestRec layout");
     if (!P.dest.empty()) HIPCHECK(hipMemcpyAsync(c.d_dest.p, P.dest.data(), P.dest.size() * sizeof(DestRec), hipMemcpyHostToDevice, s));
-    c.d_lambda.need(std::max(1, P.N));
+    c.d_lambda.need((size_t)P.N + INC_NODES);
     DevPlan &d = c.dp;
     d.nF = P.nF;
     d.fd = c.d_fd.p; d.dest = c.d_dest.p; d.child = c.d_child.p;
-    d.f_rows = c.d_i32.p + o_rows; d.f_rel = c.d_i32.p + o_rel; d.slot_blk = c.d_i32.p + o_sb; d.slot_rhs = c.d_i32.p + o_sr;
+    d.f_rows = c.d_i32.p; d.f_rel = c.d_i32.p; d.slot_blk = c.d_i32.p + o_sb; d.slot_rhs = c.d_i32.p + o_sr; d.src_idx = c.d_i32.p;
+    c.inc.o_rows = (long long)o_rows; c.inc.o_rel = (long long)o_rel;
     d.lambda = c.d_lambda.p;
     d.prof = nullptr;
     if (getenv("APRILSAM_AMD_KPROF")) { c.d_prof.need((size_t)8 * P.nF); HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)64 * P.nF, s)); d.prof = c.d_prof.p; }
-    c.d_swap.need(std::max(1, P.F)); c.d_pos.need(std::max(1, P.N));
+    c.d_swap.need((size_t)P.F + INC_FACT); c.d_pos.need((size_t)P.N + INC_NODES);
     HIPCHECK(hipMemcpyAsync(c.d_swap.p, P.fac_swap.data(), P.F, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_pos.p, P.pos.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
 
     // ---- launch tables -------------------------------------------------------------------------------------
     std::vector<int> tab;
     c.levels.assign(P.nLevels, LevelPlan());
-    const size_t small_max = (size_t)g_opt.small_lds_kb * 1024, med_max = (size_t)g_opt.medium_lds_kb * 1024;
     for (int l = 0; l < P.nLevels; l++) {
-        LevelPlan &L = c.levels[l];
-        std::vector<int> small, med, big;
-        size_t maxm = 0;
-        for (int k = P.lev_ptr[l]; k < P.lev_ptr[l + 1]; k++) {
-            int t = P.lev_fronts[k];
-            const int R = P.rows(t), C = P.cols(t);
-            maxm = std::max<size_t>(maxm, C);
-            const size_t lds_s = small_front_lds(R, C), lds_m = medium_front_lds(R);
-            if (lds_s <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); }
-            else if (lds_m <= med_max) { med.push_back(t); L.med_lds = std::max(L.med_lds, lds_m); }
-            else { big.push_back(t); L.asm_lds = std::max(L.asm_lds, scratch_bytes(R)); }
-        }
-        L.all_off = (int)tab.size(); L.n_all = P.lev_ptr[l + 1] - P.lev_ptr[l];
-        tab.insert(tab.end(), P.lev_fronts.begin() + P.lev_ptr[l], P.lev_fronts.begin() + P.lev_ptr[l + 1]);
-        L.solve_lds = (maxm + NB + 8) * 8;
-        L.small_off = (int)tab.size(); L.n_small = (int)small.size();
-        tab.insert(tab.end(), small.begin(), small.end());
-        L.med_off = (int)tab.size(); L.n_med = (int)med.size();
-        tab.insert(tab.end(), med.begin(), med.end());
-        L.n_big = (int)big.size();
-        if (big.empty()) continue;
-        std::sort(big.begin(), big.end(), [&](int a, int b) { return P.f_nsb[a] != P.f_nsb[b] ? P.f_nsb[a] > P.f_nsb[b] : a < b; });
-        int list_off = (int)tab.size();
-        tab.insert(tab.end(), big.begin(), big.end());
-        auto make = [&](int nact, auto count) {
-            Launch La; La.list_off = list_off; La.n = nact; La.pre_off = (int)tab.size();
-            int acc = 0; tab.push_back(0);
-            for (int i = 0; i < nact; i++) { acc += count(big[i]); tab.push_back(acc); }
-            La.grid = acc;
-            return La;
-        };
-        L.asm_big = make((int)big.size(), [&](int t) { return asm_chunks(P.f_nsb[t] + P.f_nub[t]); });
-        int steps = (3 * P.f_nsb[big[0]] + NB - 1) / NB;
-        for (int sidx = 0; sidx < steps; sidx++) {
-            int nact = 0;
-            while (nact < (int)big.size() && 3 * P.f_nsb[big[nact]] > sidx * NB) nact++;
-            L.panel.push_back(make(nact, [&](int t) { return panel_tiles(P.rows(t), 3 * P.f_nsb[t], sidx); }));
-            L.syrk.push_back(make(nact, [&](int t) { return syrk_tiles(P.rows(t), P.cols(t), 3 * P.f_nsb[t], sidx); }));
-        }
+        std::vector<int> fr(P.lev_fronts.begin() + P.lev_ptr[l], P.lev_fronts.begin() + P.lev_ptr[l + 1]);
+        build_level(c.levels[l], fr, tab, [&](int t, int *nsb, int *nub) { *nsb = P.f_nsb[t]; *nub = P.f_nub[t]; });
     }
     if (tab.empty()) tab.push_back(0);
-    c.d_tab.need(tab.size());
+    c.d_tab.need(tab.size() + INC_TAB);
+    c.inc.tab_used = (long long)tab.size();
     HIPCHECK(hipMemcpyAsync(c.d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipStreamSynchronize(s));      // host vectors above go out of scope
 
-    c.d_pool.need((size_t)std::max<int64_t>(P.pool_doubles, 1));
-    c.d_H.need((size_t)9 * std::max(1, P.n_slots)); c.d_x.need((size_t)3 * std::max(1, P.N));
+    const long long pool_slack = std::max<long long>(INC_POOL_MIN, P.pool_doubles / 4);
+    c.d_pool.need((size_t)std::max<int64_t>(P.pool_doubles, 1) + (size_t)pool_slack);
+    c.inc.pool_used = P.pool_doubles; c.inc.pool_cap = (long long)c.d_pool.cap;
+    c.d_H.need((size_t)9 * ((size_t)std::max(1, P.n_slots) + (size_t)5 * INC_FACT)); c.d_x.need((size_t)3 * ((size_t)P.N + INC_NODES));
+    c.inc.slots_used = P.n_slots;
+    c.inc.ready = false;
     c.d_bad.need(4); c.h_bad.need(4);
     c.st.n_fronts = P.nF; c.st.n_levels = P.nLevels; c.st.max_front_rows = P.max_rows;
     c.st.nnz_L = P.nnzL; c.st.flops_factor = P.flops; c.st.bytes_fronts = 8.0 * (double)P.pool_doubles;
@@ -539,6 +591,245 @@ static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g) {
     return false;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// incremental fast path: frozen base plan + TAIL front + regeneration of the dirty root paths only
+// ------------------------------------------------------------------------------------------------------
+static void inc_prepare(Context &c) {        // after a full (re)plan: c.plan is the new base
+    IncState &I = c.inc; const Plan &P = c.plan;
+    I.Nb = P.N; I.Fb = P.F; I.nF0 = P.nF; I.nLev0 = P.nLevels;
+    I.pos_front.assign(P.N, 0);
+    for (int t = 0; t < P.nF; t++) for (int k = 0; k < P.f_nsb[t]; k++) I.pos_front[P.f_first[t] + k] = t;
+    I.parent.assign(P.f_parent.begin(), P.f_parent.end()); I.parent.push_back(-1);
+    I.E.assign(P.nF, {}); I.xfac.assign(P.nF + 1, {});
+    I.bf_ptr.assign(P.nF + 1, 0);
+    for (int f = 0; f < P.F; f++) if (P.fac_front[f] >= 0) I.bf_ptr[P.fac_front[f] + 1]++;
+    for (int t = 0; t < P.nF; t++) I.bf_ptr[t + 1] += I.bf_ptr[t];
+    I.bf_idx.resize(P.F);
+    { std::vector<int> fill(I.bf_ptr.begin(), I.bf_ptr.end() - 1); for (int f = 0; f < P.F; f++) if (P.fac_front[f] >= 0) I.bf_idx[fill[P.fac_front[f]]++] = f; }
+    I.rel_begin.assign(P.nF + 1, 0); I.cur_nub.assign(P.nF + 1, 0); I.cur_cap.assign(P.nF + 1, 0);
+    for (int t = 0; t < P.nF; t++) { I.rel_begin[t] = (int)(I.o_rel + P.f_rows_ptr[t]); I.cur_nub[t] = P.f_nub[t]; I.cur_cap[t] = (long long)P.rows(t) * P.cols(t); }
+    I.dirty.assign(P.nF + 1, 0);
+    I.f_level.assign(P.f_level.begin(), P.f_level.end()); I.f_level.push_back(P.nLevels);
+    I.fd.resize(P.nF + 1);
+    FrontDesc &T = I.fd[P.nF];
+    memset(&T, 0, sizeof(T));
+    T.first = P.N; T.parent = -1;
+    I.base_levels = c.levels;
+    c.inc_slot_blk.clear(); c.inc_slot_rhs.clear();
+    I.ready = true;
+}
+
+// Regenerate the dirty part of the plan for nodes [.., N) / factors [Fold, F) and run the numeric phase on it.
+// Returns false (nothing enqueued) when the step does not fit the frozen structure or the reserved slack.
+static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int Nold) {
+    IncState &I = c.inc; Plan &P = c.plan;
+    if (!I.ready || N < I.Nb || Fold < I.Fb) return false;
+    const int Nb = I.Nb, nF0 = I.nF0, TAIL = nF0, m = N - Nb;
+    if (m > INC_NODES - 8 || F - I.Fb > INC_FACT - 8 || m < 1) return false;
+    const int *fa = gp.h_fa.p, *fb = gp.h_fb.p;
+    hipStream_t s = gp.stream;
+    auto local_base = [&](int t, int p) -> int {      // local block index of base position p in base front t, or -1
+        if (p >= P.f_first[t] && p < P.f_first[t] + P.f_nsb[t]) return p - P.f_first[t];
+        const int *b = P.f_rows.data() + P.f_rows_ptr[t], *e = b + P.f_nub[t];
+        const int *it = std::lower_bound(b, e, p);
+        return (it == e || *it != p) ? -1 : P.f_nsb[t] + (int)(it - b);
+    };
+    // ---- 1. owners of the new factors, tail rows along root paths ----------------------------------------------
+    for (int f = Fold; f < F; f++) {
+        const int a = fa[f], b = fb[f];
+        const bool ta = a >= Nb, tb = b >= Nb;
+        int owner;
+        if (b < 0) owner = ta ? TAIL : I.pos_front[P.pos[a]];
+        else if (ta && tb) owner = TAIL;
+        else if (ta != tb) {
+            const int j = ta ? b : a, k = ta ? a : b;
+            owner = I.pos_front[P.pos[j]];
+            for (int t = owner; t != TAIL; t = I.parent[t]) {
+                auto &E = I.E[t];
+                auto it = std::lower_bound(E.begin(), E.end(), k);
+                if (it == E.end() || *it != k) { E.insert(it, k); I.dirty[t] = 1; }
+                if (I.parent[t] < 0) I.parent[t] = TAIL;
+            }
+        } else {
+            const int pa = P.pos[a], pb = P.pos[b];
+            owner = I.pos_front[std::min(pa, pb)];
+            if (local_base(owner, std::max(pa, pb)) < 0) return false;       // would change the frozen structure
+        }
+        I.xfac[owner].push_back(f);
+        I.dirty[owner] = 1;
+    }
+    I.dirty[TAIL] = 1;
+    for (int t = 0; t < nF0; t++) if (I.dirty[t] && I.parent[t] >= 0) I.dirty[I.parent[t]] = 1;
+    // ---- 2. regenerate dirty fronts (children before parents) ----------------------------------------------------
+    std::vector<int> st_i32; std::vector<DestRec> st_dest; std::vector<ChildRec> st_child;
+    std::vector<std::vector<int>> lev_dirty(I.nLev0 + 1);
+    std::vector<int> fd_dirty;
+    std::vector<int> new_slot_blk((size_t)3 * (F - Fold), -1), new_slot_rhs((size_t)2 * (F - Fold), -1);
+    std::vector<unsigned char> new_swap(F - Fold, 0);
+    c.inc_slot_blk.resize((size_t)3 * (F - I.Fb), -1); c.inc_slot_rhs.resize((size_t)2 * (F - I.Fb), -1);
+    for (int f = Fold; f < F; f++) {                     // 5 fresh slots per new factor (3 blocks, 2 rhs segments)
+        for (int k = 0; k < 3; k++) new_slot_blk[(size_t)3 * (f - Fold) + k] = c.inc_slot_blk[(size_t)3 * (f - I.Fb) + k] = I.slots_used++;
+        for (int k = 0; k < 2; k++) new_slot_rhs[(size_t)2 * (f - Fold) + k] = c.inc_slot_rhs[(size_t)2 * (f - I.Fb) + k] = I.slots_used++;
+    }
+    const long long i32_base = I.i32_used, dest_base = I.dest_used, child_base = I.child_used;
+    auto tail_children = [&]() { std::vector<int> v; for (int t = 0; t < nF0; t++) if (I.parent[t] == TAIL) v.push_back(t); return v; };
+    struct Ent { int col, row, f, k, slot; };
+    std::vector<Ent> ents;
+    for (int t = 0; t <= TAIL; t++) {
+        if (!I.dirty[t]) continue;
+        const bool is_tail = t == TAIL;
+        const int nsb = is_tail ? m : P.f_nsb[t], nub0 = is_tail ? 0 : P.f_nub[t];
+        const std::vector<int> empty;
+        const std::vector<int> &E = is_tail ? empty : I.E[t];
+        const int nub = nub0 + (int)E.size(), nbc = nsb + nub;
+        const long long need = (long long)(3 * (nbc + 1)) * (3 * nbc);
+        FrontDesc &D = I.fd[t];
+        if (need > I.cur_cap[t]) {
+            const long long off = (I.pool_used + 31) & ~31ll;
+            if (off + need > I.pool_cap) return false;
+            D.off = off; I.pool_used = off + need; I.cur_cap[t] = need;
+        }
+        D.nsb = nsb; D.nub = nub; I.cur_nub[t] = nub;
+        if (is_tail) D.first = Nb;
+        // struct rows (positions): base struct then tail nodes (position of a tail node = its id)
+        D.rows_begin = (int)(i32_base + (long long)st_i32.size());
+        if (!is_tail) st_i32.insert(st_i32.end(), P.f_rows.begin() + P.f_rows_ptr[t], P.f_rows.begin() + P.f_rows_ptr[t + 1]);
+        st_i32.insert(st_i32.end(), E.begin(), E.end());
+        auto local = [&](int node) -> int {            // local block index of a node in this front
+            if (is_tail) return node - Nb;
+            if (node >= Nb) { auto it = std::lower_bound(E.begin(), E.end(), node); return nsb + nub0 + (int)(it - E.begin()); }
+            return local_base(t, P.pos[node]);
+        };
+        // destination records: only fronts that own factors added since the batch need new ones
+        if (!I.xfac[t].empty()) {
+            ents.clear();
+            auto add_factor = [&](int f) {
+                const int a = fa[f], b = fb[f];
+                const int la = local(a), lb = b >= 0 ? local(b) : -1;
+                if (f >= Fold) new_swap[f - Fold] = (lb >= 0 && la < lb);       // orientation of the off-diagonal block
+                const int *sb = f < I.Fb ? &P.slot_blk[(size_t)3 * f] : &c.inc_slot_blk[(size_t)3 * (f - I.Fb)];
+                const int *sr = f < I.Fb ? &P.slot_rhs[(size_t)2 * f] : &c.inc_slot_rhs[(size_t)2 * (f - I.Fb)];
+                ents.push_back({ la, la, f, 0, sb[0] }); ents.push_back({ la, -1, f, 3, sr[0] });
+                if (lb >= 0) {
+                    ents.push_back({ std::min(la, lb), std::max(la, lb), f, 1, sb[1] });
+                    ents.push_back({ lb, lb, f, 2, sb[2] }); ents.push_back({ lb, -1, f, 4, sr[1] });
+                }
+            };
+            if (!is_tail) for (int q = I.bf_ptr[t]; q < I.bf_ptr[t + 1]; q++) add_factor(I.bf_idx[q]);
+            for (int f : I.xfac[t]) add_factor(f);
+            std::sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) {
+                if (x.col != y.col) return x.col < y.col;
+                if (x.row != y.row) return x.row < y.row;
+                if (x.f != y.f) return x.f < y.f;
+                return x.k < y.k;
+            });
+            D.dest_begin = (int)(dest_base + (long long)st_dest.size());
+            for (size_t i = 0; i < ents.size(); i++) {
+                const bool fresh = i == 0 || ents[i].col != ents[i - 1].col || ents[i].row != ents[i - 1].row;
+                if (fresh) st_dest.push_back({ ents[i].row, ents[i].col, (int)(i32_base + (long long)st_i32.size()), 0 });
+                st_i32.push_back(ents[i].slot);
+                st_dest.back().src_end = -(int)(i32_base + (long long)st_i32.size());
+            }
+            D.dest_end = (int)(dest_base + (long long)st_dest.size());
+        }
+        // children: records + block maps into this front's (possibly longer) row list
+        std::vector<int> kids_tail;
+        const int *kb, *ke;
+        if (is_tail) { kids_tail = tail_children(); kb = kids_tail.data(); ke = kb + kids_tail.size(); }
+        else { kb = P.ch_idx.data() + P.ch_ptr[t]; ke = P.ch_idx.data() + P.ch_ptr[t + 1]; }
+        D.ch_begin = (int)(child_base + (long long)st_child.size());
+        for (const int *kp = kb; kp != ke; kp++) {
+            const int ch = *kp;
+            const int cnsb = P.f_nsb[ch], cnub0 = P.f_nub[ch];
+            const std::vector<int> &Ec = I.E[ch];
+            I.rel_begin[ch] = (int)(i32_base + (long long)st_i32.size());
+            if (!is_tail) st_i32.insert(st_i32.end(), P.f_rel.begin() + P.f_rows_ptr[ch], P.f_rel.begin() + P.f_rows_ptr[ch + 1]);
+            for (int k : Ec) st_i32.push_back(local(k));
+            ChildRec r;
+            r.cnu = cnub0 + (int)Ec.size(); r.cR = 3 * (cnsb + r.cnu + 1);
+            r.uoff = I.fd[ch].off + (long long)(3 * cnsb) * r.cR + 3 * cnsb;
+            r.rel_begin = I.rel_begin[ch]; r.pad = ch;
+            st_child.push_back(r);
+        }
+        D.ch_end = (int)(child_base + (long long)st_child.size());
+        D.parent = I.parent[t];
+        fd_dirty.push_back(t);
+        lev_dirty[I.f_level[t]].push_back(t);
+    }
+    if (I.i32_used + (long long)st_i32.size() > (long long)c.d_i32.cap || I.dest_used + (long long)st_dest.size() > (long long)c.d_dest.cap ||
+        I.child_used + (long long)st_child.size() > (long long)c.d_child.cap || (size_t)9 * I.slots_used > c.d_H.cap) return false;
+    // ---- 3. launch tables of the dirty fronts (transient region behind the base tables) + back-substitution LDS -----
+    std::vector<int> tab; std::vector<LevelPlan> dl(I.nLev0 + 1);
+    auto dims = [&](int t, int *nsb, int *nub) { *nsb = t == TAIL ? m : P.f_nsb[t]; *nub = I.cur_nub[t]; };
+    for (int l = 0; l <= I.nLev0; l++) if (!lev_dirty[l].empty()) build_level(dl[l], lev_dirty[l], tab, dims);
+    if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return false;
+    for (int l = 0; l <= I.nLev0; l++) {
+        if (lev_dirty[l].empty()) continue;
+        LevelPlan &L = dl[l];
+        const int sh = (int)I.tab_used;
+        L.all_off += sh; L.small_off += sh; L.med_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
+        for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
+        if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8) * 8);
+    }
+    // ---- 4. uploads ------------------------------------------------------------------------------------------------
+    if (!st_i32.empty()) HIPCHECK(hipMemcpyAsync(c.d_i32.p + I.i32_used, st_i32.data(), st_i32.size() * 4, hipMemcpyHostToDevice, s));
+    if (!st_dest.empty()) HIPCHECK(hipMemcpyAsync(c.d_dest.p + I.dest_used, st_dest.data(), st_dest.size() * sizeof(DestRec), hipMemcpyHostToDevice, s));
+    if (!st_child.empty()) HIPCHECK(hipMemcpyAsync(c.d_child.p + I.child_used, st_child.data(), st_child.size() * sizeof(ChildRec), hipMemcpyHostToDevice, s));
+    if (!tab.empty()) HIPCHECK(hipMemcpyAsync(c.d_tab.p + I.tab_used, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
+    I.i32_used += (long long)st_i32.size(); I.dest_used += (long long)st_dest.size(); I.child_used += (long long)st_child.size();
+    for (int t : fd_dirty) HIPCHECK(hipMemcpyAsync(c.d_fd.p + t, &I.fd[t], sizeof(FrontDesc), hipMemcpyHostToDevice, s));
+    if (F > Fold) {
+        HIPCHECK(hipMemcpyAsync((int *)c.dp.slot_blk + (size_t)3 * Fold, new_slot_blk.data(), new_slot_blk.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemcpyAsync((int *)c.dp.slot_rhs + (size_t)2 * Fold, new_slot_rhs.data(), new_slot_rhs.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemcpyAsync(c.d_swap.p + Fold, new_swap.data(), new_swap.size(), hipMemcpyHostToDevice, s));
+    }
+    if (N > Nold) {
+        std::vector<int> ids(N - Nold); std::vector<double> zeros(N - Nold, 0.0);
+        for (int i = Nold; i < N; i++) ids[i - Nold] = i;
+        HIPCHECK(hipMemcpyAsync(c.d_pos.p + Nold, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemcpyAsync(c.d_lambda.p + Nold, zeros.data(), zeros.size() * 8, hipMemcpyHostToDevice, s));
+        P.perm.resize(N); P.pos.resize(N);
+        for (int i = Nold; i < N; i++) { P.perm[i] = i; P.pos[i] = i; }
+    }
+    HIPCHECK(hipStreamSynchronize(s));      // staging vectors die at return; the copies are tiny
+    // ---- 5. numeric: new factors linearised, dirty fronts level by level, full back substitution, update ---------------
+    set_small_attr();
+    HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 4, s));
+    if (F > Fold)
+        hipLaunchKernelGGL(k_linearize, dim3((F - Fold + TPB - 1) / TPB), dim3(TPB), 0, s, Fold, F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
+                           gp.d_lp.p, gp.d_lp.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
+    for (int l = 0; l <= I.nLev0; l++) {
+        if (lev_dirty[l].empty()) continue;
+        const LevelPlan &L = dl[l];
+        if (L.n_small) hipLaunchKernelGGL(k_front_small, dim3(L.n_small), dim3(TPB), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
+        if (L.n_med) hipLaunchKernelGGL(k_front_medium, dim3(L.n_med), dim3(TPB_MED), L.med_lds, s, c.dp, c.d_tab.p + L.med_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
+        if (L.n_big) {
+            hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
+                               c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
+            for (size_t k = 0; k < L.panel.size(); k++) {
+                const Launch &pa = L.panel[k], &sy = L.syrk[k];
+                hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_bad.p);
+                if (sy.grid > 0) hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off, sy.n, (int)k, c.d_pool.p);
+            }
+        }
+    }
+    {   // TAIL is the root of the back substitution; its launch list is the single dirty entry of the top level
+        const LevelPlan &L = dl[I.nLev0];
+        hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
+    }
+    for (int l = I.nLev0 - 1; l >= 0; l--) {
+        const LevelPlan &L = I.base_levels[l];
+        hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
+    }
+    HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));
+    hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
+    HIPCHECK(hipGetLastError());
+    for (int t : fd_dirty) I.dirty[t] = 0;
+    c.st.n_fronts = nF0 + 1; c.st.n_levels = I.nLev0 + 1;
+    return true;
+}
+
 static void set_lambda(Context &c, GraphPack &gp, double lambda) {
     const int N = c.plan.N;
     c.h_lambda.assign(N, lambda > 0 ? lambda : 0.0);            // aprilsam.c:197-204
@@ -594,6 +885,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         param->nreordering = N;
         param->factor_num = F;
         c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = false;
+        inc_prepare(c); c.inc_F = F; c.inc_N = N;
         if (param->delta_x) {                                                // aprilsam.c:363-366
             free(param->delta_x);
             param->delta_x = (double *)calloc((size_t)3 * N, sizeof(double));
@@ -650,12 +942,18 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     const int N = gp.N, F = gp.F;
     if (!c.model.valid) c.model.batch(c.batch_nodes, c.batch_factors, gp.h_fa.p, gp.h_fb.p);      // lazily, after a batch step
     c.model.inc_begin(N, F, gp.h_fa.p, gp.h_fb.p);
-    const bool reused = prepare_plan(c, gp, g);
     upload_factors(gp);
-    c.h_lambda.assign(N, 0.0);
-    for (int i = 0; i < N; i++) if (c.plan.perm[i] < c.batch_nodes && param->tikhanov > 0) c.h_lambda[i] = param->tikhanov;
-    HIPCHECK(hipMemcpyAsync(c.d_lambda.p, c.h_lambda.data(), (size_t)8 * N, hipMemcpyHostToDevice, gp.stream));
-    run_numeric(c, gp, false, true);
+    // fast path: frozen base plan + TAIL front, only the dirty root paths are regenerated and re-factorised
+    bool reused = g_opt.inc_fast && inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N);
+    if (!reused) {                // the step does not fit the frozen structure (or slack ran out): full re-plan
+        prepare_plan(c, gp, g);
+        c.h_lambda.assign(N, 0.0);
+        for (int i = 0; i < N; i++) if (c.plan.perm[i] < c.batch_nodes && param->tikhanov > 0) c.h_lambda[i] = param->tikhanov;
+        HIPCHECK(hipMemcpyAsync(c.d_lambda.p, c.h_lambda.data(), (size_t)8 * N, hipMemcpyHostToDevice, gp.stream));
+        run_numeric(c, gp, false, true);
+        inc_prepare(c);
+    }
+    c.inc_F = F; c.inc_N = N;
     HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
     HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
     HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, gp.stream));
@@ -821,6 +1119,7 @@ int resident_end(april_graph_t *g, april_graph_cholesky_param_t *param) {
     memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
     param->nreordering = N; param->factor_num = F;
     c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = false;
+    inc_prepare(c); c.inc_F = F; c.inc_N = N;
     return 0;
 }
 int batch_resident(april_graph_t *g, april_graph_cholesky_param_t *param, int iters, double *chi2_out, double *ms_out) {
@@ -895,6 +1194,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "trust_factor_cache") g_opt.trust_factor_cache = (int)v;
     else if (k == "small_lds_kb") g_opt.small_lds_kb = (int)v;
     else if (k == "medium_lds_kb") g_opt.medium_lds_kb = (int)v;
+    else if (k == "inc_fast") g_opt.inc_fast = (int)v;
     else return -1;
     return 0;
 }

@@ -168,7 +168,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
         struct U { int front, col, row, src, rhs; };
         std::vector<U> all; all.reserve(bd.size() + rd.size());
         for (const Dest &d : bd) all.push_back({ d.front, d.col, d.row, d.src, 0 });
-        for (const Dest &d : rd) all.push_back({ d.front, d.col, P.f_nsb[d.front] + P.f_nub[d.front], d.src, 1 });
+        for (const Dest &d : rd) all.push_back({ d.front, d.col, -1, d.src, 1 });     // brow -1 = the rhs row
         std::sort(all.begin(), all.end(), [](const U &x, const U &y) { return std::tie(x.front, x.col, x.row, x.src) < std::tie(y.front, y.col, y.row, y.src); });
         P.dest_front_ptr.assign(nT + 1, 0); P.dest.clear();
         P.slot_blk.assign((size_t)3 * F, -1); P.slot_rhs.assign((size_t)2 * F, -1);

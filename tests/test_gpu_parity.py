@@ -209,14 +209,43 @@ def test_tutorial_incremental_mode_matches_reference_golden(lib):
         assert np.max(np.abs(st - G[f"states_{k}"])) < STATE_ATOL
 
 
-def test_incremental_demo_matches_reference_schedule(lib):
+@pytest.mark.parametrize("inc_fast", [1, 0])
+def test_incremental_demo_matches_reference_schedule(lib, inc_fast):
     """Config 3 (first 650 poses of the M3500 demo, deterministic schedule): per-step chi^2 within 1e-6 of the
     reference's april_graph_cholesky_inc, IDENTICAL batch fall-back steps (232, 350, 508, 591 nodes), same
     final states.  Golden: tests/golden/m3500_inc_demo.npz, produced by the unmodified reference."""
     G = golden("m3500_inc_demo.npz")
-    n = 650
-    res = harness.run_demo(lib, datasets.m3500_arrays(), max_poses=n, deterministic=True)
+    n = 650 if inc_fast else 360          # inc_fast=0: full re-plan per step (the slow, structure-agnostic path)
+    lib.set_option("inc_fast", inc_fast)
+    try:
+        res = harness.run_demo(lib, datasets.m3500_arrays(), max_poses=n, deterministic=True)
+    finally:
+        lib.set_option("inc_fast", 1)
     assert np.array_equal(res["was_batch"], G["was_batch"][:n])
-    assert (np.nonzero(res["was_batch"])[0] + 1).tolist() == [1, 232, 350, 508, 591]
+    assert (np.nonzero(res["was_batch"])[0] + 1).tolist() == [k for k in (1, 232, 350, 508, 591) if k <= n]
     rel = np.abs(res["chi2"] - G["chi2"][:n]) / np.maximum(G["chi2"][:n], 1e-9)
     assert np.max(rel) < CHI2_RTOL, (int(np.argmax(rel)), float(np.max(rel)))
+
+
+def test_incremental_general_usage_falls_back_to_replanning(lib, oracle):
+    """factors between two OLD poses and steps without a new pose do not fit the frozen structure of the fast
+    path: the library must notice and re-plan; results = exact solve of the incremental system on all poses
+    (naffected > 5 here, so the reference updates every pose too)"""
+    arr = datasets.random_pose_graph(60, 30, 8)
+    st, fa, fb, z, W = arr
+    keep = np.ones(len(fa), bool)
+    late = [k for k in range(len(fa)) if fb[k] >= 0 and abs(int(fa[k]) - int(fb[k])) > 1][-6:]
+    keep[late] = False
+    g = lib.new_graph(); g.build_from_arrays(st, fa[keep], fb[keep], z[keep], W[keep]); p = lib.new_param(nthreshold=10**6)
+    g.cholesky(p)
+    lp = g.l_points()
+    for k in late:                       # six loop closures between existing poses, one call each, no new pose
+        g.add_factor_xyt(int(fa[k]), int(fb[k]), z[k], W[k])
+    p.c.batch_time = 1e300
+    g.cholesky_inc(p)
+    order = np.concatenate([np.nonzero(keep)[0], late])
+    lam = np.full(len(st), 1e-4)
+    dx = oracle.solve_system(lp, lp, fa[order], fb[order], z[order], W[order], lam)
+    pred = lp + dx; pred[:, 2] = [oracle.mod2pi(v) for v in pred[:, 2]]
+    assert np.max(np.abs(g.states() - pred)) < 1e-8
+    p.destroy(); g.destroy()
