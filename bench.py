@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lattice", action="store_true")
+    ap.add_argument("--no-inc", action="store_true")
     a = ap.parse_args()
 
     import torch
@@ -217,6 +218,33 @@ def main():
             p.destroy(); g.destroy()
         except Exception as e:   # the headline line must survive a failure of the extra
             out["lattice100k"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_inc:
+        # config 3: the pose-by-pose M3500 demo (examples/aprilsam_demo.c semantics, deterministic schedule)
+        try:
+            from aprilsam_amd import harness
+            from tests.support.oracle_binding import REFLIB
+            G = np.load(os.path.join(ROOT, "tests", "golden", "m3500_inc_demo.npz"))
+            res = harness.run_demo(lib, datasets.m3500_arrays(), deterministic=True)
+            ms = res["ms"]
+            rel = np.abs(res["chi2"] - G["chi2"]) / np.maximum(G["chi2"], 1e-9)
+            inc = {"workload": "M3500 demo, 3500 poses added one by one: 1 batch + 3499 april_graph_cholesky_inc calls through the "
+                               "reference API (host objects in/out every call), nthreshold 100, delta 0.1/0.1, wall-clock rule off",
+                   "total_ms": float(ms.sum()), "mean_ms": float(ms.mean()), "median_ms": float(np.median(ms)),
+                   "p99_ms": float(np.percentile(ms, 99)), "max_ms": float(ms.max()),
+                   "chi2_max_relerr_vs_reference": float(rel.max()), "final_chi2": float(res["chi2"][-1]),
+                   "batch_fallbacks": int(res["was_batch"].sum()) - 1,
+                   "fallback_schedule_identical": bool(np.array_equal(res["was_batch"], G["was_batch"])),
+                   "max_abs_state_err": float(np.max(np.abs(res["final_states"] - G["final_states"])))}
+            if os.path.exists(REFLIB) and not a.no_cpu_baseline:
+                ref = host.SolverLib(REFLIB)
+                rr = harness.run_demo(ref, datasets.m3500_arrays(), deterministic=True)
+                rms = rr["ms"]
+                inc["reference_cpu_same_host"] = {"total_ms": float(rms.sum()), "mean_ms": float(rms.mean()), "median_ms": float(np.median(rms)),
+                                                   "p99_ms": float(np.percentile(rms, 99)), "max_ms": float(rms.max()), "cores": 1}
+                inc["speedup_total_vs_reference"] = float(rms.sum() / ms.sum())
+            out["m3500_incremental"] = inc
+        except Exception as e:
+            out["m3500_incremental"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(arrays)
         out["cpu_baseline"]["host"] = f"{os.cpu_count()} logical cores visible; reference is single-threaded"

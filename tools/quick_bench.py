@@ -2,7 +2,7 @@
 """Short bench summary for optimisation loops: python tools/quick_bench.py [--lattice]"""
 import json, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-args = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--no-cpu-baseline"]
+args = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--no-cpu-baseline", "--no-inc"]
 if "--lattice" not in sys.argv:
     args.append("--no-lattice")
 r = subprocess.run(args, capture_output=True, text=True)
