@@ -76,22 +76,28 @@ struct HopcroftKarp {
     }
 };
 
-// unit-capacity max-flow (Dinic) used for exact vertex-separator refinement inside a band
+// unit-capacity max-flow (Dinic) used for exact vertex-separator refinement inside a band.  Flat arrays
+// (linked adjacency lists) that are reused across calls: the ordering runs on every batch fall-back of
+// the incremental path, so its constant factors are on a hot host path.
 struct Dinic {
-    struct E { int to, cap; };
-    std::vector<E> e; std::vector<std::vector<int>> g; std::vector<int> lvl, it;
-    explicit Dinic(int n) : g(n), lvl(n), it(n) {}
-    void add(int u, int v, int c) { g[u].push_back((int)e.size()); e.push_back({ v, c }); g[v].push_back((int)e.size()); e.push_back({ u, 0 }); }
+    struct E { int to, cap, next; };
+    std::vector<E> e; std::vector<int> head, lvl, it, q;
+    void reset(int n) { e.clear(); head.assign(n, -1); lvl.assign(n, -1); it.assign(n, -1); q.clear(); q.reserve(n); }
+    void add(int u, int v, int c) {
+        e.push_back({ v, c, head[u] }); head[u] = (int)e.size() - 1;
+        e.push_back({ u, 0, head[v] }); head[v] = (int)e.size() - 1;
+    }
     bool bfs(int s, int t) {
         std::fill(lvl.begin(), lvl.end(), -1);
-        std::vector<int> q{ s }; lvl[s] = 0;
-        for (size_t h = 0; h < q.size(); h++) for (int id : g[q[h]]) if (e[id].cap > 0 && lvl[e[id].to] < 0) { lvl[e[id].to] = lvl[q[h]] + 1; q.push_back(e[id].to); }
+        q.clear(); q.push_back(s); lvl[s] = 0;
+        for (size_t h = 0; h < q.size(); h++)
+            for (int id = head[q[h]]; id >= 0; id = e[id].next)
+                if (e[id].cap > 0 && lvl[e[id].to] < 0) { lvl[e[id].to] = lvl[q[h]] + 1; q.push_back(e[id].to); }
         return lvl[t] >= 0;
     }
     int dfs(int u, int t, int f) {
         if (u == t) return f;
-        for (int &i = it[u]; i < (int)g[u].size(); i++) {
-            int id = g[u][i];
+        for (int &id = it[u]; id >= 0; id = e[id].next) {
             if (e[id].cap > 0 && lvl[e[id].to] == lvl[u] + 1) {
                 int d = dfs(e[id].to, t, std::min(f, e[id].cap));
                 if (d > 0) { e[id].cap -= d; e[id ^ 1].cap += d; return d; }
@@ -101,7 +107,7 @@ struct Dinic {
     }
     int run(int s, int t) {
         int flow = 0;
-        while (bfs(s, t)) { std::fill(it.begin(), it.end(), 0); while (int f = dfs(s, t, 1 << 29)) flow += f; }
+        while (bfs(s, t)) { it = head; while (int f = dfs(s, t, 1 << 29)) flow += f; }
         return flow;
     }
 };
@@ -116,6 +122,7 @@ struct Dissector {
     int next_label = 0;
     std::vector<int> dist, loc; // scratch (size N)
     std::vector<char> side;     // scratch (size N)
+    Dinic dinic;                // scratch of refine_band
 
     Dissector(int N_, const std::vector<int> &ap_, const std::vector<int> &ai_, const double *xy_, int leaf_, NDTree &t)
         : N(N_), ap(ap_), ai(ai_), xy(xy_), leaf(leaf_), tree(t), label(N_, 0), dist(N_, -1), loc(N_, -1), side(N_, 0) {}
@@ -201,7 +208,7 @@ struct Dissector {
         const int nb = (int)band.size();
         bool core0 = false, core1 = false;
         for (int i = 0; i < nb; i++) loc[band[i]] = i;
-        Dinic fl(2 * nb + 2);
+        Dinic &fl = dinic; fl.reset(2 * nb + 2);
         const int SRC = 2 * nb, SNK = 2 * nb + 1, INF = 1 << 28;
         for (int i = 0; i < nb; i++) {
             int u = band[i];
@@ -303,8 +310,10 @@ struct Dissector {
         if ((int)comp.size() <= leaf) { for (int v : comp) label[v] = -1; new_node(std::move(comp), parent); return; }
         Split cand[4];
         split_geometric(comp, L, cand[0]);
-        split_geometric(comp, L, cand[1], 1.5707963267948966);          // orthogonal axis
-        split_geometric(comp, L, cand[2], 0.7853981633974483);          // diagonal
+        if ((int)comp.size() > 8 * leaf) {                              // the extra directions only pay near the top of the tree
+            split_geometric(comp, L, cand[1], 1.5707963267948966);      // orthogonal axis
+            split_geometric(comp, L, cand[2], 0.7853981633974483);      // diagonal
+        }
         split_bfs(comp, L, cand[3]);
         Split *best = nullptr, *second = nullptr;
         for (Split &c : cand) {
@@ -314,7 +323,7 @@ struct Dissector {
         }
         if (best && (int)comp.size() > 4 * leaf) {
             for (Split *c : { best, second }) {
-                if (!c) continue;
+                if (!c || (c == second && second->cost > 1.25 * best->cost)) continue;
                 for (int pass = 0; pass < 2; pass++) { double before = c->cost; refine_band(comp, L, *c, 2); if (c->cost >= before) break; }
             }
             if (second && second->cost < best->cost) best = second;

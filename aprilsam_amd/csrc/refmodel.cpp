@@ -197,9 +197,12 @@ void RefModel::inc_begin(int n_nodes, int n_factors, const int *fa, const int *f
     root = ord[N - 1];
 }
 
-// aprilsam.c:721-779.  x: 3 doubles per node (node order).  visit(node, update) is called for every pose the
-// reference touches: update == true -> node->update(x) (state, delta_X); false -> only delta_X = x.
-void RefModel::solve_visit(const double *x, double dxy, double dth, const std::function<void(int, bool)> &visit) {
+// aprilsam.c:721-779, split in two: the traversal is purely structural (labels + tree), so it can be planned
+// BEFORE the numbers exist — the GPU then only back-substitutes the fronts that hold a visited pose.
+// plan_visit: poses solve_node touches, in order; update == true -> node->update(x) (state, delta_X),
+// false -> only delta_X = x (an unmarked child reached when naffected <= 5; the walk stops there).
+void RefModel::plan_visit(std::vector<Visit> &out) {
+    out.clear();
     std::vector<int> cptr(N + 1, 0), cidx(N);
     for (int i = 0; i < N; i++) if (parent[i] >= 0) cptr[parent[i] + 1]++;
     for (int i = 0; i < N; i++) cptr[i + 1] += cptr[i];
@@ -207,18 +210,29 @@ void RefModel::solve_visit(const double *x, double dxy, double dth, const std::f
     std::vector<int> stack; stack.push_back(root);
     while (!stack.empty()) {
         const int n = stack.back(); stack.pop_back();
-        const double *xi = x + 3 * (size_t)n;
-        if (std::fabs(xi[0]) > dxy || std::fabs(xi[1]) > dxy || std::fabs(xi[2]) > dth) {
-            if (!relin[n]) { relin[n] = 1; start_over++; }
-        }
         bool update = true;
         if (naffected > 5) changed[n] = 0;
         else if (changed[n] == 1) changed[n] = 0;
         else update = false;
-        visit(n, update);
+        out.push_back({ n, update });
         if (!update) continue;                       // :769 returns before the children
         for (int k = cptr[n]; k < cptr[n + 1]; k++) stack.push_back(cidx[k]);
     }
+}
+// relinearisation counter over the visited poses (aprilsam.c:741-751)
+void RefModel::count_relinearized(const double *x, double dxy, double dth, const std::vector<Visit> &visits) {
+    for (const Visit &v : visits) {
+        const double *xi = x + 3 * (size_t)v.node;
+        if (std::fabs(xi[0]) > dxy || std::fabs(xi[1]) > dxy || std::fabs(xi[2]) > dth) {
+            if (!relin[v.node]) { relin[v.node] = 1; start_over++; }
+        }
+    }
+}
+void RefModel::solve_visit(const double *x, double dxy, double dth, const std::function<void(int, bool)> &visit) {
+    std::vector<Visit> v;
+    plan_visit(v);
+    count_relinearized(x, dxy, dth, v);
+    for (const Visit &w : v) visit(w.node, w.update);
 }
 
 }  // namespace asam

@@ -21,6 +21,9 @@ struct RefModel {
     void add_factor_edges(int a, int b);
     void batch(int n_nodes, int n_factors, const int *fa, const int *fb);
     void inc_begin(int n_nodes, int n_factors, const int *fa, const int *fb);
+    struct Visit { int node; bool update; };
+    void plan_visit(std::vector<Visit> &out);
+    void count_relinearized(const double *x, double dxy, double dth, const std::vector<Visit> &visits);
     void solve_visit(const double *x, double dxy, double dth, const std::function<void(int, bool)> &visit);
 };
 

@@ -254,6 +254,9 @@ struct IncState {
     std::vector<char> dirty;
     std::vector<int> f_level;               // base levels, TAIL = nLev0
     std::vector<LevelPlan> base_levels;     // launch tables of all fronts per level for the back substitution
+    // staging for the per-step uploads (members: the async copies read them until the step's final sync)
+    std::vector<int> st_i32, st_tab, st_sb, st_sr, st_ids; std::vector<DestRec> st_dest; std::vector<ChildRec> st_child;
+    std::vector<unsigned char> st_sw; std::vector<double> st_zeros; std::vector<char> need;
 };
 
 struct Context {
@@ -285,6 +288,8 @@ struct Context {
     int batch_nodes = 0;                  // #nodes at the last batch step (those carry the Tikhonov term)
     IncState inc;
     int inc_F = 0, inc_N = 0;                      // factors / nodes folded into the factorisation so far
+    std::vector<RefModel::Visit> visits;
+    std::vector<int> base_tab;                     // host copy of the launch tables of the base plan
     std::vector<int> inc_slot_blk, inc_slot_rhs;   // slots of the factors added since the base plan (3 / 2 per factor)
     RefModel model;                       // the reference's tree / counters (refmodel.cpp), rebuilt lazily after a batch
     int batch_factors = 0;                // #factors at the last batch step
@@ -435,6 +440,7 @@ static void upload_plan(Context &c, hipStream_t s) {
     if (tab.empty()) tab.push_back(0);
     c.d_tab.need(tab.size() + INC_TAB);
     c.inc.tab_used = (long long)tab.size();
+    c.base_tab = tab;
     HIPCHECK(hipMemcpyAsync(c.d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipStreamSynchronize(s));      // host vectors above go out of scope
 
@@ -621,7 +627,7 @@ static void inc_prepare(Context &c) {        // after a full (re)plan: c.plan is
 
 // Regenerate the dirty part of the plan for nodes [.., N) / factors [Fold, F) and run the numeric phase on it.
 // Returns false (nothing enqueued) when the step does not fit the frozen structure or the reserved slack.
-static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int Nold) {
+static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int Nold, const std::vector<RefModel::Visit> *needed) {
     IncState &I = c.inc; Plan &P = c.plan;
     if (!I.ready || N < I.Nb || Fold < I.Fb) return false;
     const int Nb = I.Nb, nF0 = I.nF0, TAIL = nF0, m = N - Nb;
@@ -661,11 +667,12 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     I.dirty[TAIL] = 1;
     for (int t = 0; t < nF0; t++) if (I.dirty[t] && I.parent[t] >= 0) I.dirty[I.parent[t]] = 1;
     // ---- 2. regenerate dirty fronts (children before parents) ----------------------------------------------------
-    std::vector<int> st_i32; std::vector<DestRec> st_dest; std::vector<ChildRec> st_child;
+    std::vector<int> &st_i32 = I.st_i32; std::vector<DestRec> &st_dest = I.st_dest; std::vector<ChildRec> &st_child = I.st_child;
+    st_i32.clear(); st_dest.clear(); st_child.clear();
     std::vector<std::vector<int>> lev_dirty(I.nLev0 + 1);
     std::vector<int> fd_dirty;
-    std::vector<int> new_slot_blk((size_t)3 * (F - Fold), -1), new_slot_rhs((size_t)2 * (F - Fold), -1);
-    std::vector<unsigned char> new_swap(F - Fold, 0);
+    std::vector<int> &new_slot_blk = I.st_sb, &new_slot_rhs = I.st_sr; std::vector<unsigned char> &new_swap = I.st_sw;
+    new_slot_blk.assign((size_t)3 * (F - Fold), -1); new_slot_rhs.assign((size_t)2 * (F - Fold), -1); new_swap.assign(F - Fold, 0);
     c.inc_slot_blk.resize((size_t)3 * (F - I.Fb), -1); c.inc_slot_rhs.resize((size_t)2 * (F - I.Fb), -1);
     for (int f = Fold; f < F; f++) {                     // 5 fresh slots per new factor (3 blocks, 2 rhs segments)
         for (int k = 0; k < 3; k++) new_slot_blk[(size_t)3 * (f - Fold) + k] = c.inc_slot_blk[(size_t)3 * (f - I.Fb) + k] = I.slots_used++;
@@ -759,9 +766,25 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     if (I.i32_used + (long long)st_i32.size() > (long long)c.d_i32.cap || I.dest_used + (long long)st_dest.size() > (long long)c.d_dest.cap ||
         I.child_used + (long long)st_child.size() > (long long)c.d_child.cap || (size_t)9 * I.slots_used > c.d_H.cap) return false;
     // ---- 3. launch tables of the dirty fronts (transient region behind the base tables) + back-substitution LDS -----
-    std::vector<int> tab; std::vector<LevelPlan> dl(I.nLev0 + 1);
+    std::vector<int> &tab = I.st_tab; tab.clear(); std::vector<LevelPlan> dl(I.nLev0 + 1);
     auto dims = [&](int t, int *nsb, int *nub) { *nsb = t == TAIL ? m : P.f_nsb[t]; *nub = I.cur_nub[t]; };
     for (int l = 0; l <= I.nLev0; l++) if (!lev_dirty[l].empty()) build_level(dl[l], lev_dirty[l], tab, dims);
+    std::vector<int> bs_off(I.nLev0, 0), bs_n(I.nLev0, 0);       // restricted back substitution: fronts per level
+    if (needed) {
+        I.need.assign(nF0 + 1, 0);
+        for (const RefModel::Visit &v : *needed) {
+            int t = v.node >= Nb ? TAIL : I.pos_front[P.pos[v.node]];
+            while (t >= 0 && t != TAIL && !I.need[t]) { I.need[t] = 1; t = I.parent[t]; }
+        }
+        for (int l = 0; l < I.nLev0; l++) bs_off[l] = -1;
+        for (int l = I.nLev0 - 1; l >= 0; l--) {
+            bs_off[l] = (int)(I.tab_used + (long long)tab.size());
+            for (int k = I.base_levels[l].all_off; k < I.base_levels[l].all_off + I.base_levels[l].n_all; k++) {
+                const int t = c.base_tab[k];
+                if (I.need[t]) { tab.push_back(t); bs_n[l]++; }
+            }
+        }
+    }
     if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return false;
     for (int l = 0; l <= I.nLev0; l++) {
         if (lev_dirty[l].empty()) continue;
@@ -785,14 +808,14 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         HIPCHECK(hipMemcpyAsync(c.d_swap.p + Fold, new_swap.data(), new_swap.size(), hipMemcpyHostToDevice, s));
     }
     if (N > Nold) {
-        std::vector<int> ids(N - Nold); std::vector<double> zeros(N - Nold, 0.0);
+        std::vector<int> &ids = I.st_ids; std::vector<double> &zeros = I.st_zeros;
+        ids.resize(N - Nold); zeros.assign(N - Nold, 0.0);
         for (int i = Nold; i < N; i++) ids[i - Nold] = i;
         HIPCHECK(hipMemcpyAsync(c.d_pos.p + Nold, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, s));
         HIPCHECK(hipMemcpyAsync(c.d_lambda.p + Nold, zeros.data(), zeros.size() * 8, hipMemcpyHostToDevice, s));
         P.perm.resize(N); P.pos.resize(N);
         for (int i = Nold; i < N; i++) { P.perm[i] = i; P.pos[i] = i; }
     }
-    HIPCHECK(hipStreamSynchronize(s));      // staging vectors die at return; the copies are tiny
     // ---- 5. numeric: new factors linearised, dirty fronts level by level, full back substitution, update ---------------
     set_small_attr();
     HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 4, s));
@@ -818,9 +841,15 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         const LevelPlan &L = dl[I.nLev0];
         hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
     }
-    for (int l = I.nLev0 - 1; l >= 0; l--) {
-        const LevelPlan &L = I.base_levels[l];
-        hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
+    if (!needed) {                                   // every pose is visited: all fronts, level by level
+        for (int l = I.nLev0 - 1; l >= 0; l--) {
+            const LevelPlan &L = I.base_levels[l];
+            hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
+        }
+    } else {                                         // only the fronts holding a visited pose, and their ancestors
+        for (int l = I.nLev0 - 1; l >= 0; l--)
+            if (bs_n[l] > 0)
+                hipLaunchKernelGGL(k_backsolve, dim3((unsigned)bs_n[l]), dim3(TPB), I.base_levels[l].solve_lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p);
     }
     HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
@@ -944,7 +973,10 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     c.model.inc_begin(N, F, gp.h_fa.p, gp.h_fb.p);
     upload_factors(gp);
     // fast path: frozen base plan + TAIL front, only the dirty root paths are regenerated and re-factorised
-    bool reused = g_opt.inc_fast && inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N);
+    std::vector<RefModel::Visit> &visits = c.visits;
+    c.model.plan_visit(visits);                      // structural: which poses the reference's solve_node touches
+    const bool partial = c.model.naffected <= 5;     // aprilsam.c:755: otherwise the whole tree is walked
+    bool reused = g_opt.inc_fast && inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, partial ? &visits : nullptr);
     if (!reused) {                // the step does not fit the frozen structure (or slack ran out): full re-plan
         prepare_plan(c, gp, g);
         c.h_lambda.assign(N, 0.0);
@@ -969,14 +1001,16 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
     for (int i = 0; i < N; i++) ns[i]->UID = i;                          // aprilsam.c:474
     const double *x = gp.h_dx.p;                                          // dx per node; NaN where the solve produced NaN
-    c.model.solve_visit(x, param->delta_xy, param->delta_theta, [&](int n, bool update) {
+    c.model.count_relinearized(x, param->delta_xy, param->delta_theta, visits);
+    for (const RefModel::Visit &vis : visits) {
+        const int n = vis.node; const bool update = vis.update;
         april_graph_node_t *nd = ns[n];
         const double *dx = x + (size_t)3 * n;
         memcpy(nd->delta_X, dx, 24);                                      // aprilsam.c:752-754
-        if (!update) return;
-        if (std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2])) return;   // april_graph_xyt.c:304-305
+        if (!update) continue;
+        if (std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2])) continue;   // april_graph_xyt.c:304-305
         memcpy(nd->state, gp.h_state.p + (size_t)3 * n, 24);              // l_point + dx, theta wrapped (k_update_states)
-    });
+    }
     if (param->ordering) free(param->ordering);
     param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
     memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
