@@ -73,6 +73,15 @@ int aprilsam_amd_reference_order(int n_nodes, int n_factors, const int *fa, cons
     if (out_parent) memcpy(out_parent, m.parent.data(), sizeof(int) * (size_t)n_nodes);
     return 0;
 }
+int aprilsam_amd_shard_begin(april_graph_t *graph, april_graph_cholesky_param_t *param, int rank, int world) { return asam::shard_begin(graph, param, rank, world); }
+long long aprilsam_amd_shard_info(const april_graph_cholesky_param_t *param, int what, long long *out, long long cap) { return asam::shard_info(param, what, out, cap); }
+int aprilsam_amd_shard_step(april_graph_t *graph, april_graph_cholesky_param_t *param, int op, int arg) { return asam::shard_step(graph, param, op, arg); }
+int aprilsam_amd_shard_copy(april_graph_t *graph, april_graph_cholesky_param_t *param, int kind, long long offset, long long count, void *buf, int dir) {
+    return asam::shard_copy(graph, param, kind, offset, count, buf, dir);
+}
+double aprilsam_amd_shard_chi2_local(april_graph_t *graph, april_graph_cholesky_param_t *param) { return asam::shard_chi2_local(graph, param); }
+void aprilsam_amd_shard_end(april_graph_cholesky_param_t *param) { asam::shard_end(param); }
+
 // test handle on the bookkeeping model (host logic only)
 void *aprilsam_amd_refmodel_create(void) { return new asam::RefModel(); }
 void aprilsam_amd_refmodel_destroy(void *m) { delete (asam::RefModel *)m; }

@@ -30,6 +30,12 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
 void drop_context(const april_graph_cholesky_param_t *p);
 void drop_graph_pack(const april_graph_t *g);
 bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out);
+int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank, int world);
+long long shard_info(const april_graph_cholesky_param_t *param, int what, long long *out, long long cap);
+int shard_step(april_graph_t *g, april_graph_cholesky_param_t *param, int op, int arg);
+int shard_copy(april_graph_t *g, april_graph_cholesky_param_t *param, int kind, long long offset, long long count, void *buf, int dir);
+double shard_chi2_local(april_graph_t *g, april_graph_cholesky_param_t *param);
+void shard_end(const april_graph_cholesky_param_t *param);
 int debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts);
 int api_device_count();
 int api_set_device(int d);

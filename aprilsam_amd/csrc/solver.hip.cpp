@@ -465,6 +465,38 @@ static void set_small_attr() {
     });
 }
 
+// kernels of one level of the factorisation (small LDS fronts, medium, big multi-workgroup path)
+template <class Tic, class Toc>
+static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc) {
+    if (L.n_small) {
+        tic(K_FRONT_SMALL);
+        hipLaunchKernelGGL(k_front_small, dim3(L.n_small), dim3(TPB), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
+        toc();
+    }
+    if (L.n_med) {
+        tic(K_FRONT_MEDIUM);
+        hipLaunchKernelGGL(k_front_medium, dim3(L.n_med), dim3(TPB_MED), L.med_lds, s, c.dp, c.d_tab.p + L.med_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
+        toc();
+    }
+    if (L.n_big) {
+        tic(K_ASSEMBLE_BIG);
+        hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
+                           c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
+        toc();
+        for (size_t k = 0; k < L.panel.size(); k++) {
+            const Launch &pa = L.panel[k], &sy = L.syrk[k];
+            tic(K_PANEL_BIG);
+            hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_bad.p);
+            toc();
+            if (sy.grid > 0) {
+                tic(K_SYRK_BIG);
+                hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off, sy.n, (int)k, c.d_pool.p);
+                toc();
+            }
+        }
+    }
+}
+
 // enqueue: linearise -> per level {assemble+factor} -> back substitution -> state update
 // ev != null: record stage events (0 start, 1 after linearise, 2 after factor, 3 after solve+update)
 // ktime: bracket EVERY kernel launch with its own HIP event pair on this stream (c.k_ev / c.k_ids)
@@ -484,44 +516,11 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 4, s));
     if (c.dp.prof) HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)64 * P.nF, s));
     tic(K_LINEARIZE);
-    hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
+    hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                        gp.d_lp.p, unary_at_lp ? gp.d_lp.p : gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
     toc();
     if (ev) HIPCHECK(hipEventRecord(ev[1], s));
-    for (int l = 0; l < P.nLevels; l++) {
-        const LevelPlan &L = c.levels[l];
-        if (L.n_small) {
-            tic(K_FRONT_SMALL);
-            hipLaunchKernelGGL(k_front_small, dim3(L.n_small), dim3(TPB), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p,
-                               c.d_H.p, c.d_bad.p);
-            toc();
-        }
-        if (L.n_med) {
-            tic(K_FRONT_MEDIUM);
-            hipLaunchKernelGGL(k_front_medium, dim3(L.n_med), dim3(TPB_MED), L.med_lds, s, c.dp, c.d_tab.p + L.med_off, c.d_pool.p,
-                               c.d_H.p, c.d_bad.p);
-            toc();
-        }
-        if (L.n_big) {
-            tic(K_ASSEMBLE_BIG);
-            hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
-                               c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
-            toc();
-            for (size_t k = 0; k < L.panel.size(); k++) {
-                const Launch &pa = L.panel[k], &sy = L.syrk[k];
-                tic(K_PANEL_BIG);
-                hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off,
-                                   pa.n, (int)k, c.d_pool.p, c.d_bad.p);
-                toc();
-                if (sy.grid > 0) {
-                    tic(K_SYRK_BIG);
-                    hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off,
-                                       sy.n, (int)k, c.d_pool.p);
-                    toc();
-                }
-            }
-        }
-    }
+    for (int l = 0; l < P.nLevels; l++) enqueue_factor_level(c, c.levels[l], s, tic, toc);
     if (ev) HIPCHECK(hipEventRecord(ev[2], s));
     for (int l = P.nLevels - 1; l >= 0; l--) {
         const LevelPlan &L = c.levels[l];
@@ -820,7 +819,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     set_small_attr();
     HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 4, s));
     if (F > Fold)
-        hipLaunchKernelGGL(k_linearize, dim3((F - Fold + TPB - 1) / TPB), dim3(TPB), 0, s, Fold, F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
+        hipLaunchKernelGGL(k_linearize, dim3((F - Fold + TPB - 1) / TPB), dim3(TPB), 0, s, Fold, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                            gp.d_lp.p, gp.d_lp.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
     for (int l = 0; l <= I.nLev0; l++) {
         if (lev_dirty[l].empty()) continue;
@@ -1211,6 +1210,193 @@ int debug_front_times(const april_graph_cholesky_param_t *param, long long *out,
     HIPCHECK(hipMemcpy(out, it->second->d_prof.p, (size_t)64 * n, hipMemcpyDeviceToHost));
     return n;
 }
+// ------------------------------------------------------------------------------------------------------
+// multi-GPU: nested-dissection subtree sharding (BASELINE.json config 5)
+//
+// Every rank builds the SAME plan (the planner is deterministic).  The assembly tree is split by proportional
+// mapping: the root owns the rank range [0, world); a front with range [lo, hi) is owned by rank lo and hands the
+// halves [lo, mid) / [mid, hi) to its children, greedily balanced by subtree flops; ranges of size 1 make a whole
+// subtree local.  Per Gauss-Newton iteration the only data crossing ranks are
+//   * up:   the Schur update block of a front whose parent lives on another rank (one contiguous slab of its
+//           frontal array: columns 3*nsb.. end), sent point-to-point to the parent's owner,
+//   * down: the solved x of the "top" fronts (range > 1 rank), a few thousand doubles each, broadcast.
+// The library only provides the per-level compute steps and the slab copies; the exchange itself is done by the
+// host driver with RCCL through torch.distributed (aprilsam_amd/shard.py) — one process per GPU.
+// ------------------------------------------------------------------------------------------------------
+struct ShardState {
+    int rank = 0, world = 1;
+    std::vector<int> owner;                  // per front
+    std::vector<char> top;                   // per front: rank range spans more than one rank
+    std::vector<LevelPlan> levels;           // launch tables of the fronts THIS rank owns, per level
+    DBuf<int> d_flist; int n_flist = 0;      // factors owned by this rank's fronts
+    std::vector<long long> xfer;             // transfers up: level, front, src, dst, offset (doubles), count (doubles)
+    std::vector<long long> bcast;            // broadcasts down: level, front, owner, first position, own blocks
+};
+static std::unordered_map<const void *, std::unique_ptr<ShardState>> g_shard;
+
+int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank, int world) {
+    if (zsize(g->nodes) == 0 || zsize(g->factors) == 0 || world < 1 || rank < 0 || rank >= world) return -1;
+    ensure_device();
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context &c = ctx_for(param);
+    GraphPack &gp = pack_for(g);
+    pack_factors(gp, g);
+    pack_states(gp, g, false);
+    prepare_plan(c, gp, g);
+    upload_factors(gp);
+    set_lambda(c, gp, param->tikhanov);
+    const Plan &P = c.plan;
+    auto &S = *(g_shard[param] = std::make_unique<ShardState>());
+    S.rank = rank; S.world = world;
+    // subtree work (flops proxy) per front
+    std::vector<double> work(P.nF, 0.0);
+    for (int t = 0; t < P.nF; t++) {
+        const double ns = 3.0 * P.f_nsb[t], m = 3.0 * (P.f_nsb[t] + P.f_nub[t]);
+        work[t] += ns * m * m + 1.0;
+        if (P.f_parent[t] >= 0) work[P.f_parent[t]] += work[t];
+    }
+    std::vector<int> lo(P.nF, 0), hi(P.nF, world);
+    S.owner.assign(P.nF, 0); S.top.assign(P.nF, 0);
+    // roots first (fronts are numbered children-before-parents, so walk downwards from the end)
+    std::vector<std::vector<int>> kids(P.nF);
+    for (int t = 0; t < P.nF; t++) if (P.f_parent[t] >= 0) kids[P.f_parent[t]].push_back(t);
+    {   // several roots (disconnected graph): spread them like children of a virtual root
+        std::vector<int> roots; for (int t = 0; t < P.nF; t++) if (P.f_parent[t] < 0) roots.push_back(t);
+        std::sort(roots.begin(), roots.end(), [&](int a, int b) { return work[a] != work[b] ? work[a] > work[b] : a < b; });
+        for (size_t i = 0; i < roots.size(); i++) { lo[roots[i]] = (int)(i % world) * 0; hi[roots[i]] = world; }
+    }
+    for (int t = P.nF - 1; t >= 0; t--) {
+        S.owner[t] = lo[t]; S.top[t] = (hi[t] - lo[t]) > 1;
+        if (kids[t].empty()) continue;
+        if (hi[t] - lo[t] <= 1) { for (int ch : kids[t]) { lo[ch] = lo[t]; hi[ch] = hi[t]; } continue; }
+        const int mid = (lo[t] + hi[t]) / 2;
+        std::vector<int> ks(kids[t]);
+        std::sort(ks.begin(), ks.end(), [&](int a, int b) { return work[a] != work[b] ? work[a] > work[b] : a < b; });
+        double wa = 0, wb = 0;
+        for (int ch : ks) {
+            if (wa <= wb) { wa += work[ch]; lo[ch] = lo[t]; hi[ch] = mid; }
+            else { wb += work[ch]; lo[ch] = mid; hi[ch] = hi[t]; }
+        }
+    }
+    // launch tables of the owned fronts, appended behind the full tables
+    std::vector<int> tab;
+    S.levels.assign(P.nLevels, LevelPlan());
+    for (int l = 0; l < P.nLevels; l++) {
+        std::vector<int> fr;
+        for (int k = P.lev_ptr[l]; k < P.lev_ptr[l + 1]; k++) if (S.owner[P.lev_fronts[k]] == rank) fr.push_back(P.lev_fronts[k]);
+        build_level(S.levels[l], fr, tab, [&](int t, int *nsb, int *nub) { *nsb = P.f_nsb[t]; *nub = P.f_nub[t]; });
+        LevelPlan &L = S.levels[l];
+        const int sh = (int)c.inc.tab_used;
+        L.all_off += sh; L.small_off += sh; L.med_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
+        for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
+    }
+    if (c.inc.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return -3;
+    if (!tab.empty()) HIPCHECK(hipMemcpyAsync(c.d_tab.p + c.inc.tab_used, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, gp.stream));
+    // factors owned by this rank's fronts
+    std::vector<int> fl;
+    for (int f = 0; f < P.F; f++) if (P.fac_front[f] >= 0 && S.owner[P.fac_front[f]] == rank) fl.push_back(f);
+    S.n_flist = (int)fl.size();
+    S.d_flist.need(std::max<size_t>(1, fl.size()));
+    if (!fl.empty()) HIPCHECK(hipMemcpyAsync(S.d_flist.p, fl.data(), fl.size() * 4, hipMemcpyHostToDevice, gp.stream));
+    // exchange lists
+    for (int t = 0; t < P.nF; t++) {
+        const int par = P.f_parent[t];
+        if (par >= 0 && S.owner[par] != S.owner[t]) {
+            const long long R = P.rows(t), C = P.cols(t), ns = 3ll * P.f_nsb[t];
+            const long long v[6] = { P.f_level[t], t, S.owner[t], S.owner[par], P.f_off[t] + ns * R, (C - ns) * R };
+            S.xfer.insert(S.xfer.end(), v, v + 6);
+        }
+        if (S.top[t]) { const long long v[5] = { P.f_level[t], t, S.owner[t], P.f_first[t], P.f_nsb[t] }; S.bcast.insert(S.bcast.end(), v, v + 5); }
+    }
+    HIPCHECK(hipMemsetAsync(c.d_x.p, 0, (size_t)24 * gp.N, gp.stream));     // poses of other ranks' subtrees simply do not move here
+    HIPCHECK(hipStreamSynchronize(gp.stream));
+    c.st.n_nodes = gp.N; c.st.n_factors = gp.F;
+    return 0;
+}
+// what: 0 -> #levels, 1 -> xfer (6 per entry), 2 -> bcast (5 per entry), 3 -> owner per front.  Returns count written (or needed if out == null)
+long long shard_info(const april_graph_cholesky_param_t *param, int what, long long *out, long long cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_shard.find(param); auto ic = g_ctx.find(param);
+    if (it == g_shard.end() || ic == g_ctx.end()) return -1;
+    const ShardState &S = *it->second;
+    std::vector<long long> v;
+    if (what == 0) v = { ic->second->plan.nLevels, ic->second->plan.nF, ic->second->plan.N };
+    else if (what == 1) v = S.xfer;
+    else if (what == 2) v = S.bcast;
+    else if (what == 3) v.assign(S.owner.begin(), S.owner.end());
+    if (out) for (long long i = 0; i < (long long)v.size() && i < cap; i++) out[i] = v[i];
+    return (long long)v.size();
+}
+// op: 0 relinearise + linearise owned factors; 1 factor level `arg`; 2 back-substitute level `arg`; 3 state update; 4 stream sync
+int shard_step(april_graph_t *g, april_graph_cholesky_param_t *param, int op, int arg) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_shard.find(param); auto ic = g_ctx.find(param);
+    if (it == g_shard.end() || ic == g_ctx.end()) return -1;
+    ShardState &S = *it->second; Context &c = *ic->second;
+    GraphPack &gp = pack_for(g);
+    hipStream_t s = gp.stream;
+    HIPCHECK(hipSetDevice(g_device));
+    set_small_attr();
+    const int N = gp.N;
+    auto nop = [](int) {}; auto nop0 = []() {};
+    if (op == 0) {
+        HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 4, s));
+        if (S.n_flist)
+            hipLaunchKernelGGL(k_linearize, dim3((S.n_flist + TPB - 1) / TPB), dim3(TPB), 0, s, 0, S.n_flist, (const int *)S.d_flist.p, gp.d_fa.p, gp.d_fb.p,
+                               gp.d_z.p, gp.d_W.p, gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
+    } else if (op == 1) {
+        enqueue_factor_level(c, S.levels[arg], s, nop, nop0);
+    } else if (op == 2) {
+        const LevelPlan &L = S.levels[arg];
+        if (L.n_all) hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
+    } else if (op == 3) {
+        HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));
+        hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
+    } else if (op == 4) {
+        HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        return c.h_bad.p[0] ? -2 : 0;
+    }
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+// copy `count` doubles between the front pool (kind 0, offset in doubles) or the solution vector x (kind 1, offset in
+// doubles by elimination position*3) and a caller buffer (device or host pointer); dir 0: library -> buffer, 1: buffer -> library
+int shard_copy(april_graph_t *g, april_graph_cholesky_param_t *param, int kind, long long offset, long long count, void *buf, int dir) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto ic = g_ctx.find(param);
+    if (ic == g_ctx.end()) return -1;
+    Context &c = *ic->second;
+    GraphPack &gp = pack_for(g);
+    double *p = (kind == 0 ? c.d_pool.p : c.d_x.p) + offset;
+    HIPCHECK(hipMemcpyAsync(dir == 0 ? buf : (void *)p, dir == 0 ? (void *)p : buf, (size_t)count * 8, hipMemcpyDefault, gp.stream));
+    HIPCHECK(hipStreamSynchronize(gp.stream));
+    return 0;
+}
+// chi^2 of the factors owned by this rank, at the resident states (sum over ranks = april_graph_chi2)
+double shard_chi2_local(april_graph_t *g, april_graph_cholesky_param_t *param) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_shard.find(param); auto ic = g_ctx.find(param);
+    if (it == g_shard.end() || ic == g_ctx.end()) return -1;
+    GraphPack &gp = pack_for(g);
+    const Plan &P = ic->second->plan; const ShardState &S = *it->second;
+    hipStream_t s = gp.stream;
+    hipLaunchKernelGGL(k_chi2, dim3((gp.F + TPB - 1) / TPB), dim3(TPB), 0, s, gp.F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p, gp.d_state.p, gp.d_chi2f.p);
+    std::vector<double> h(gp.F);
+    HIPCHECK(hipMemcpyAsync(h.data(), gp.d_chi2f.p, (size_t)8 * gp.F, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    double acc = 0;
+    for (int f = 0; f < gp.F; f++) if (P.fac_front[f] >= 0 && S.owner[P.fac_front[f]] == S.rank) acc += h[f];
+    return acc;
+}
+void shard_end(const april_graph_cholesky_param_t *param) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_shard.find(param);
+    if (it != g_shard.end()) { it->second->d_flist.release(); g_shard.erase(it); }
+}
+
 int api_device_count() { return device_count(); }
 int api_set_device(int d) {
     int n = device_count();
