@@ -222,8 +222,8 @@ static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp) {
 // ------------------------------------------------------------------------------------------------------
 // solver context — one per april_graph_cholesky_param_t pointer
 // ------------------------------------------------------------------------------------------------------
-enum { K_LINEARIZE = 0, K_FRONT_SMALL, K_FRONT_MEDIUM, K_ASSEMBLE_BIG, K_PANEL_BIG, K_SYRK_BIG, K_BACKSOLVE, K_UPDATE, NKERN };
-static const char *const KNAMES[NKERN] = { "k_linearize", "k_front_small", "k_front_medium", "k_assemble_big", "k_panel_big", "k_syrk_big", "k_backsolve", "k_update_states" };
+enum { K_LINEARIZE = 0, K_FRONT_SMALL, K_FRONT_MEDIUM, K_ASSEMBLE_BIG, K_DIAG_BIG, K_PANEL_BIG, K_SYRK_BIG, K_BACKSOLVE, K_UPDATE, NKERN };
+static const char *const KNAMES[NKERN] = { "k_linearize", "k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big", "k_backsolve", "k_update_states" };
 struct Launch { int list_off, pre_off, n, grid; };     // offsets into the int launch-table buffer
 
 struct LevelPlan {
@@ -273,7 +273,7 @@ struct Context {
     DBuf<int> d_pos;
     DBuf<long long> d_prof;
     // numeric state
-    DBuf<double> d_pool, d_H, d_x;
+    DBuf<double> d_pool, d_H, d_x, d_diag;   // d_diag: factored diagonal blocks of the current panel step, one per active big front
     DBuf<int> d_bad;
     HBuf<int> h_bad;
     std::vector<double> h_lambda;
@@ -298,7 +298,7 @@ struct Context {
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
-        d_pool.release(); d_H.release(); d_x.release(); d_bad.release(); h_bad.release();
+        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release();
         if (gexec) (void)hipGraphExecDestroy(gexec);
         gexec = nullptr;
         if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
@@ -347,7 +347,7 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
         const size_t lds_s = small_front_lds(R, C), lds_m = medium_front_lds(R);
         if (lds_s <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); }
         else if (lds_m <= med_max) { med.push_back(t); L.med_lds = std::max(L.med_lds, lds_m); }
-        else { big.push_back(t); L.asm_lds = std::max(L.asm_lds, scratch_bytes(R)); }
+        else { big.push_back(t); L.asm_lds = std::max(L.asm_lds, big_scratch_bytes(R)); }
     }
     // longest-processing-time first: the widest fronts of a level start first
     std::sort(small.begin(), small.end(), [&](int a, int b) { int ra = rows(a), rb = rows(b); return ra != rb ? ra > rb : a < b; });
@@ -451,6 +451,7 @@ static void upload_plan(Context &c, hipStream_t s) {
     c.inc.slots_used = P.n_slots;
     c.inc.ready = false;
     c.d_bad.need(4); c.h_bad.need(4);
+    { int mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, c.levels[l].n_big); c.d_diag.need((size_t)(mx + 64) * NB * (NB + 1)); }
     c.st.n_fronts = P.nF; c.st.n_levels = P.nLevels; c.st.max_front_rows = P.max_rows;
     c.st.nnz_L = P.nnzL; c.st.flops_factor = P.flops; c.st.bytes_fronts = 8.0 * (double)P.pool_doubles;
 }
@@ -485,8 +486,11 @@ static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, 
         toc();
         for (size_t k = 0; k < L.panel.size(); k++) {
             const Launch &pa = L.panel[k], &sy = L.syrk[k];
+            tic(K_DIAG_BIG);
+            hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
+            toc();
             tic(K_PANEL_BIG);
-            hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_bad.p);
+            hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
             toc();
             if (sy.grid > 0) {
                 tic(K_SYRK_BIG);
@@ -513,7 +517,7 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     };
     auto toc = [&]() { if (ktime) { HIPCHECK(hipEventRecord(c.k_ev[nev + 1], s)); nev += 2; } };
     if (ev) HIPCHECK(hipEventRecord(ev[0], s));
-    HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 4, s));
+    HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 16, s));
     if (c.dp.prof) HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)64 * P.nF, s));
     tic(K_LINEARIZE);
     hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
@@ -817,7 +821,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     }
     // ---- 5. numeric: new factors linearised, dirty fronts level by level, full back substitution, update ---------------
     set_small_attr();
-    HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 4, s));
+    HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 16, s));
     if (F > Fold)
         hipLaunchKernelGGL(k_linearize, dim3((F - Fold + TPB - 1) / TPB), dim3(TPB), 0, s, Fold, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                            gp.d_lp.p, gp.d_lp.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
@@ -831,7 +835,8 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
                                c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
             for (size_t k = 0; k < L.panel.size(); k++) {
                 const Launch &pa = L.panel[k], &sy = L.syrk[k];
-                hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_bad.p);
+                hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
+                hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
                 if (sy.grid > 0) hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off, sy.n, (int)k, c.d_pool.p);
             }
         }
@@ -1117,9 +1122,15 @@ int resident_sync(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (it == g_ctx.end()) return -1;
     Context &c = *it->second;
     GraphPack &gp = pack_for(g);
-    HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, gp.stream));
+    HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 16, hipMemcpyDeviceToHost, gp.stream));
     HIPCHECK(hipStreamSynchronize(gp.stream));
     c.st.not_spd = c.h_bad.p[0] != 0;
+    if (c.h_bad.p[0] && getenv("APRILSAM_AMD_DEBUG")) {
+        const int t = c.h_bad.p[1];
+        fprintf(stderr, "aprilsam_amd: bad pivot: front %d kernel %d step %d", t, c.h_bad.p[2], c.h_bad.p[3]);
+        if (t >= 0 && t < c.plan.nF) fprintf(stderr, " (nsb %d nub %d level %d off %lld)", c.plan.f_nsb[t], c.plan.f_nub[t], c.plan.f_level[t], (long long)c.plan.f_off[t]);
+        fprintf(stderr, "\n");
+    }
     return c.h_bad.p[0] ? -2 : 0;
 }
 double resident_chi2(april_graph_t *g) {
@@ -1342,7 +1353,7 @@ int shard_step(april_graph_t *g, april_graph_cholesky_param_t *param, int op, in
     auto nop = [](int) {}; auto nop0 = []() {};
     if (op == 0) {
         HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
-        HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 4, s));
+        HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 16, s));
         if (S.n_flist)
             hipLaunchKernelGGL(k_linearize, dim3((S.n_flist + TPB - 1) / TPB), dim3(TPB), 0, s, 0, S.n_flist, (const int *)S.d_flist.p, gp.d_fa.p, gp.d_fb.p,
                                gp.d_z.p, gp.d_W.p, gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);

@@ -32,12 +32,12 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak; HBM peak from MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-FLOP_KERNELS = {"k_front_small", "k_front_medium", "k_syrk_big", "k_panel_big"}
+FLOP_KERNELS = {"k_front_small", "k_front_medium", "k_syrk_big", "k_panel_big", "k_diag_big"}
 
 
 def kernel_profile(lib, p):
-    ms = (C.c_double * 8)(); calls = (C.c_longlong * 8)(); fl = (C.c_double * 8)(); by = (C.c_double * 8)()
-    names = (C.c_char_p * 8)()
+    ms = (C.c_double * 16)(); calls = (C.c_longlong * 16)(); fl = (C.c_double * 16)(); by = (C.c_double * 16)()
+    names = (C.c_char_p * 16)()
     n = lib.dll.aprilsam_amd_kernel_profile(p.ptr, ms, calls, fl, by, names)
     return [dict(name=names[k].decode(), ms=ms[k], calls=calls[k], flops=fl[k], bytes=by[k]) for k in range(n)]
 
@@ -170,7 +170,7 @@ def main():
                 launches_per_step=dom["launches_per_iter"], kernel_ms_per_step=dom["ms_per_iter"],
                 algorithmic_work_per_step=dom["flops"] if dom["name"] in FLOP_KERNELS else dom["bytes"],
                 measured="HIP events around every launch of this kernel on the solver stream, instrumented pass of the same K steps")
-    factorise_ms = sum(k["ms_per_iter"] for k in prof if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_panel_big", "k_syrk_big"))
+    factorise_ms = sum(k["ms_per_iter"] for k in prof if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big"))
 
     out = {
         "metric": "Gauss-Newton iterations/sec + factorise ms on M3500 (chi2 match <=1e-6)",
@@ -212,7 +212,7 @@ def main():
                 "reference_cpu_s_per_iter_survey_container": 44.8,
                 "nnz_L": ls["nnz_L"], "sum_cj2": ls["flops_factor"], "fronts": ls["n_fronts"], "levels": ls["n_levels"],
                 "kernels_ms_per_step": {k["name"]: round(k["ms"] / 3, 4) for k in lp},
-                "factor_tflops": ls["flops_factor"] / (1e-3 * sum(k["ms"] / 3 for k in lp if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_panel_big", "k_syrk_big"))) / 1e12,
+                "factor_tflops": ls["flops_factor"] / (1e-3 * sum(k["ms"] / 3 for k in lp if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big"))) / 1e12,
             }
             lib.dll.aprilsam_amd_resident_end(g.ptr, p.ptr)
             p.destroy(); g.destroy()

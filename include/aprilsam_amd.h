@@ -218,7 +218,7 @@ int    aprilsam_amd_resident_sync(april_graph_t *graph, april_graph_cholesky_par
 double aprilsam_amd_resident_chi2(april_graph_t *graph);
 int    aprilsam_amd_resident_end(april_graph_t *graph, april_graph_cholesky_param_t *param);
 /* Per-kernel totals of the mode-1 passes since resident_begin (ms, launches) and the ALGORITHMIC flops /
- * bytes one iteration asks of each kernel (SURVEY.md §8(d) conventions).  Arrays of 8; returns the
+ * bytes one iteration asks of each kernel (SURVEY.md §8(d) conventions).  Arrays of 16; returns the
  * number of kernels filled; names[k] points at static strings. */
 int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls,
                                 double *flops, double *bytes, const char **names);

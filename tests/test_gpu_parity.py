@@ -249,3 +249,18 @@ def test_incremental_general_usage_falls_back_to_replanning(lib, oracle):
     pred = lp + dx; pred[:, 2] = [oracle.mod2pi(v) for v in pred[:, 2]]
     assert np.max(np.abs(g.states() - pred)) < 1e-8
     p.destroy(); g.destroy()
+
+
+def test_lattice_200k_big_path_is_race_free(lib):
+    """K = 450 (202 500 poses): hundreds of multi-workgroup fronts per level.  Guards the inter-workgroup hazard the
+    panel step once had (row tiles re-reading a diagonal block another workgroup was overwriting): the step must
+    factor (no bad pivot) and Gauss-Newton must make progress, twice in a row with identical results."""
+    runs = []
+    for _ in range(2):
+        g = lib.new_graph(); lib.dll.aprilsam_amd_make_lattice(g.ptr, 450); p = lib.new_param()
+        chi2, ms = g.batch_resident(p, 2)
+        assert p.stats()["not_spd"] == 0
+        assert chi2[1] < 0.03 * chi2[0] and chi2[2] <= chi2[1]
+        runs.append(chi2)
+        p.destroy(); g.destroy()
+    assert np.array_equal(runs[0], runs[1])
