@@ -166,7 +166,17 @@ def main():
     else:
         ach = dom["bytes"] / dur_s / 1e9
         roof = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
-    roof.update(kernel=dom["name"], traffic=None, avg_launch_us=1e3 * dom["ms"] / max(1, dom["calls"]),
+    # HBM traffic of that kernel per launch from the committed PMC passes (profiles/, separate rocprofv3 --pmc runs of
+    # this same workload): (2 x FETCH_SIZE + WRITE_SIZE) KB — the x2 on the read side is the gfx950 correction of
+    # MI355X_MICROARCH.md section HBM (calibrated there for wide coalesced reads; our 8-byte loads are uncalibrated)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))["counters"]
+        traffic = 1024.0 * (2.0 * pmc["FETCH_SIZE"][dom["name"]]["kb_per_dispatch"] + pmc["WRITE_SIZE"][dom["name"]]["kb_per_dispatch"])
+    except Exception:
+        pass
+    roof.update(kernel=dom["name"], traffic=traffic, traffic_source="profiles/r01_pmc_hbm.json (bytes per launch)" if traffic else None,
+                avg_launch_us=1e3 * dom["ms"] / max(1, dom["calls"]),
                 launches_per_step=dom["launches_per_iter"], kernel_ms_per_step=dom["ms_per_iter"],
                 algorithmic_work_per_step=dom["flops"] if dom["name"] in FLOP_KERNELS else dom["bytes"],
                 measured="HIP events around every launch of this kernel on the solver stream, instrumented pass of the same K steps")
