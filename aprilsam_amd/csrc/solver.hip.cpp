@@ -224,7 +224,7 @@ static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp) {
 // ------------------------------------------------------------------------------------------------------
 enum { K_LINEARIZE = 0, K_FRONT_SMALL, K_FRONT_MEDIUM, K_ASSEMBLE_BIG, K_DIAG_BIG, K_PANEL_BIG, K_SYRK_BIG, K_BACKSOLVE, K_UPDATE, NKERN };
 static const char *const KNAMES[NKERN] = { "k_linearize", "k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big", "k_backsolve", "k_update_states" };
-struct Launch { int list_off, pre_off, n, grid; };     // offsets into the int launch-table buffer
+struct Launch { int list_off, pre_off, n, grid; bool single = false; };   // single: every front has exactly one work item     // offsets into the int launch-table buffer
 
 struct LevelPlan {
     int small_off = 0, n_small = 0; size_t small_lds = 0;      // fronts handled by k_front_small
@@ -367,7 +367,7 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
         Launch La; La.list_off = list_off; La.n = nact; La.pre_off = (int)tab.size();
         int acc = 0; tab.push_back(0);
         for (int i = 0; i < nact; i++) { acc += count(big[i]); tab.push_back(acc); }
-        La.grid = acc;
+        La.grid = acc; La.single = acc == nact;
         return La;
     };
     L.asm_big = make((int)big.size(), [&](int t) { return asm_chunks(cols(t) / 3); });
@@ -486,12 +486,18 @@ static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, 
         toc();
         for (size_t k = 0; k < L.panel.size(); k++) {
             const Launch &pa = L.panel[k], &sy = L.syrk[k];
-            tic(K_DIAG_BIG);
-            hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
-            toc();
-            tic(K_PANEL_BIG);
-            hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
-            toc();
+            if (pa.single) {          // one row tile per front: diagonal block + row solves in one launch
+                tic(K_PANEL_BIG);
+                hipLaunchKernelGGL(k_diagpanel_big, dim3(pa.n), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_bad.p);
+                toc();
+            } else {
+                tic(K_DIAG_BIG);
+                hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
+                toc();
+                tic(K_PANEL_BIG);
+                hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
+                toc();
+            }
             if (sy.grid > 0) {
                 tic(K_SYRK_BIG);
                 hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off, sy.n, (int)k, c.d_pool.p);
@@ -835,8 +841,11 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
                                c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
             for (size_t k = 0; k < L.panel.size(); k++) {
                 const Launch &pa = L.panel[k], &sy = L.syrk[k];
-                hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
-                hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
+                if (pa.single) hipLaunchKernelGGL(k_diagpanel_big, dim3(pa.n), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_bad.p);
+                else {
+                    hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
+                    hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
+                }
                 if (sy.grid > 0) hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off, sy.n, (int)k, c.d_pool.p);
             }
         }
