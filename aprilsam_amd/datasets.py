@@ -90,3 +90,14 @@ def random_pose_graph(n_nodes, extra_edges, seed, spread=10.0):
         Wk = M @ M.T + np.diag([20.0, 20.0, 50.0])
         W[k] = ((Wk + Wk.T) / 2).reshape(9)
     return with_prior(states, fa, fb, z, W, first=bool(seed % 2))
+
+
+def write_vertex_edge_text(path, states, fa, fb, z, W):
+    """inverse of parse_vertex_edge_text (lossless: 17 significant digits)"""
+    with open(path, "w") as f:
+        for i, s in enumerate(states):
+            f.write("VERTEX2 %d %.17g %.17g %.17g\n" % (i, s[0], s[1], s[2]))
+        for k in range(len(fa)):
+            w = W[k]
+            f.write("EDGE2 %d %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n" % (
+                fa[k], fb[k], z[k][0], z[k][1], z[k][2], w[0], w[1], w[4], w[8], w[2], w[5]))

@@ -1,0 +1,53 @@
+"""The C driver examples/aprilsam_demo_amd.c (counterpart of the reference's examples/aprilsam_demo.c, same flags)
+compiled with gcc against include/aprilsam_amd.h and linked to libaprilsam_amd.so."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from aprilsam_amd import datasets
+from tests.conftest import golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "aprilsam_demo_amd")
+    libdir = os.path.join(ROOT, "aprilsam_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "aprilsam_demo_amd.c"),
+                           "-L" + libdir, "-laprilsam_amd", "-Wl,-rpath," + libdir, "-lm", "-o", exe])
+    return exe
+
+
+def test_c_driver_compiles_as_plain_c_and_parses_its_flags(built, tmp_path):
+    exe = _build(tmp_path)
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage:" in r.stderr
+    txt = str(tmp_path / "m.txt")
+    datasets.write_vertex_edge_text(txt, *datasets.m3500_arrays())
+    st, fa, fb, z, W = datasets.parse_vertex_edge_text(txt)             # lossless round trip of the loader format
+    a = datasets.m3500_arrays()
+    assert np.array_equal(st, a[0]) and np.array_equal(z, a[3]) and np.array_equal(W, a[4]) and np.array_equal(fa, a[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["inc", "batch"])
+def test_c_driver_reproduces_the_reference_demo(built, tmp_path, mode):
+    exe = _build(tmp_path)
+    txt = str(tmp_path / "m.txt")
+    datasets.write_vertex_edge_text(txt, *datasets.m3500_arrays())
+    n = 300 if mode == "inc" else 120
+    args = [exe, "--datapath", txt, "--max_poses", str(n), "--nthreshold", "100", "--delta_xy", "0.1", "--delta_theta", "0.1"]
+    if mode == "batch":
+        args.append("--batch_update_only")
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    chi2 = np.array([float(x) for x in re.findall(r"Chi squared error: ([-0-9.eE+]+)", r.stdout)])
+    assert len(chi2) == n
+    if mode == "inc":
+        G = golden("m3500_inc_demo.npz")["chi2"][:n]
+        assert np.max(np.abs(chi2 - G) / np.maximum(G, 1e-6)) < 1e-5      # the driver prints %f: 6 decimals
+    else:
+        assert chi2[0] == 0.0 and np.all(np.isfinite(chi2)) and chi2[-1] < 50.0
