@@ -231,7 +231,7 @@ struct LevelPlan {
     int med_off = 0, n_med = 0; size_t med_lds = 0;            // fronts handled by k_front_medium
     int n_big = 0; size_t asm_lds = 0;
     Launch asm_big{};                                          // k_assemble_big
-    std::vector<Launch> panel, syrk;                           // per panel step
+    std::vector<Launch> panel, syrk, syrkw;                    // per panel step: diag+panel, narrow update, wide update (grid 0 unless the step closes an outer block)
     int all_off = 0, n_all = 0; size_t solve_lds = 0;          // every front (k_backsolve)
 };
 
@@ -372,11 +372,17 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     };
     L.asm_big = make((int)big.size(), [&](int t) { return asm_chunks(cols(t) / 3); });
     int steps = (3 * nsb_of(big[0]) + NB - 1) / NB;
+    auto active = [&](int sidx) { int nact = 0; while (nact < (int)big.size() && 3 * nsb_of(big[nact]) > sidx * NB) nact++; return nact; };
     for (int sidx = 0; sidx < steps; sidx++) {
-        int nact = 0;
-        while (nact < (int)big.size() && 3 * nsb_of(big[nact]) > sidx * NB) nact++;
+        const int nact = active(sidx);
         L.panel.push_back(make(nact, [&](int t) { return panel_tiles(rows(t), 3 * nsb_of(t), sidx); }));
-        L.syrk.push_back(make(nact, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), sidx); }));
+        L.syrk.push_back(make(nact, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), sidx, sidx + 1, 0); }));
+        if ((sidx + 1) % OBP == 0 || sidx + 1 == steps) {
+            const int s_lo = sidx / OBP * OBP;
+            L.syrkw.push_back(make(active(s_lo), [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, sidx + 1, 1); }));
+        } else {
+            L.syrkw.push_back(Launch{ 0, 0, 0, 0, false });
+        }
     }
 }
 
@@ -467,6 +473,37 @@ static void set_small_attr() {
 }
 
 // kernels of one level of the factorisation (small LDS fronts, medium, big multi-workgroup path)
+// panel steps of the big fronts of one level: per NB-column panel {diagonal block, row solves, narrow update};
+// after every OBP panels one wide update with K = OBP * NB (kernels.hip.h: syrk_range)
+template <class Tic, class Toc>
+static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc) {
+    for (size_t k = 0; k < L.panel.size(); k++) {
+        const Launch &pa = L.panel[k], &sy = L.syrk[k], &sw = L.syrkw[k];
+        if (pa.single) {          // one row tile per front: diagonal block + row solves in one launch
+            tic(K_PANEL_BIG);
+            hipLaunchKernelGGL(k_diagpanel_big, dim3(pa.n), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_bad.p);
+            toc();
+        } else {
+            tic(K_DIAG_BIG);
+            hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
+            toc();
+            tic(K_PANEL_BIG);
+            hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
+            toc();
+        }
+        if (sy.grid > 0) {
+            tic(K_SYRK_BIG);
+            hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off, sy.n, (int)k, (int)k + 1, 0, c.d_pool.p);
+            toc();
+        }
+        if (sw.grid > 0) {
+            tic(K_SYRK_BIG);
+            hipLaunchKernelGGL(k_syrk_big, dim3(sw.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sw.list_off, c.d_tab.p + sw.pre_off, sw.n, (int)k / OBP * OBP, (int)k + 1, 1, c.d_pool.p);
+            toc();
+        }
+    }
+}
+
 template <class Tic, class Toc>
 static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc) {
     if (L.n_small) {
@@ -484,26 +521,7 @@ static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, 
         hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
                            c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
         toc();
-        for (size_t k = 0; k < L.panel.size(); k++) {
-            const Launch &pa = L.panel[k], &sy = L.syrk[k];
-            if (pa.single) {          // one row tile per front: diagonal block + row solves in one launch
-                tic(K_PANEL_BIG);
-                hipLaunchKernelGGL(k_diagpanel_big, dim3(pa.n), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_bad.p);
-                toc();
-            } else {
-                tic(K_DIAG_BIG);
-                hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
-                toc();
-                tic(K_PANEL_BIG);
-                hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
-                toc();
-            }
-            if (sy.grid > 0) {
-                tic(K_SYRK_BIG);
-                hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off, sy.n, (int)k, c.d_pool.p);
-                toc();
-            }
-        }
+        enqueue_big_steps(c, L, s, tic, toc);
     }
 }
 
@@ -802,6 +820,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         L.all_off += sh; L.small_off += sh; L.med_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
         for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
         if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8) * 8);
     }
     // ---- 4. uploads ------------------------------------------------------------------------------------------------
@@ -839,15 +858,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         if (L.n_big) {
             hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
                                c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
-            for (size_t k = 0; k < L.panel.size(); k++) {
-                const Launch &pa = L.panel[k], &sy = L.syrk[k];
-                if (pa.single) hipLaunchKernelGGL(k_diagpanel_big, dim3(pa.n), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_bad.p);
-                else {
-                    hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
-                    hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
-                }
-                if (sy.grid > 0) hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off, sy.n, (int)k, c.d_pool.p);
-            }
+            enqueue_big_steps(c, L, s, [](int) {}, []() {});
         }
     }
     {   // TAIL is the root of the back substitution; its launch list is the single dirty entry of the top level
@@ -1310,6 +1321,7 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
         L.all_off += sh; L.small_off += sh; L.med_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
         for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
     }
     if (c.inc.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return -3;
     if (!tab.empty()) HIPCHECK(hipMemcpyAsync(c.d_tab.p + c.inc.tab_used, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, gp.stream));

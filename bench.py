@@ -17,6 +17,11 @@ Rank 0 prints ONE JSON line with the contract fields plus
                  did not travel, the C port (oracle/liboracle.so), timed on this box's host, 1 thread
   parity       — max relative chi^2 error of 10 iterations vs the reference golden (tests/golden)
   lattice100k  — config 4 (99 856 poses) ms/iteration measured the same way, for BASELINE.md's second target
+  lattice1m    — config 5 (10^6 poses, 3 994 003 factors): at N = 1 the single-GPU time per iteration; at N > 1 the SAME
+                 graph solved once by all N ranks together — nested-dissection subtrees sharded over the ranks
+                 (aprilsam_amd/shard.py), Schur slabs and separator solutions exchanged over RCCL — i.e. strong scaling
+                 of one solve, reported beside (never instead of) the replica throughput that is `value`.  A watchdog
+                 prints the line without this extra if the exchange does not finish in time.
 """
 import argparse
 import ctypes as C
@@ -102,6 +107,58 @@ def setup_dist(world, backend, device):
     return dist.barrier, max_over_ranks
 
 
+# chi^2 of the 1000 x 1000 lattice at the generator's initial states and after 1 / 2 Gauss-Newton iterations, from the
+# single-GPU path (profiles/r01_lattice1m.json); the sharded solve must reproduce them
+LATTICE1M_CHI2 = [236446240.54074645, 4636226.273819329, 4491095.9102143]      # after 0, 1 and 3 iterations
+
+
+def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iters=2):
+    """config 5.  world == 1: resident single-GPU iterations.  world > 1: one solve sharded over all ranks."""
+    import torch
+    t0 = time.perf_counter()
+    g = lib.new_graph(); nfac = lib.dll.aprilsam_amd_make_lattice(g.ptr, K); p = lib.new_param()
+    res = {"workload": f"synthetic {K}x{K} Manhattan lattice, {K * K} poses / {nfac} factors (config 5)", "n_gpus": world}
+    lib.dll.aprilsam_amd_resident_chi2.restype = C.c_double
+    if world == 1:
+        assert lib.dll.aprilsam_amd_resident_begin(g.ptr, p.ptr) == 0
+        res["setup_s_incl_ordering_symbolic_upload"] = time.perf_counter() - t0
+        chi = [lib.dll.aprilsam_amd_resident_chi2(g.ptr)]
+        lib.dll.aprilsam_amd_resident_steps(g.ptr, p.ptr, 1, 0); assert lib.dll.aprilsam_amd_resident_sync(g.ptr, p.ptr) == 0
+        chi.append(lib.dll.aprilsam_amd_resident_chi2(g.ptr))
+        dt = timed_steps(lib, g, p, iters, sync_all, barrier)
+        chi.append(lib.dll.aprilsam_amd_resident_chi2(g.ptr))
+        lib.dll.aprilsam_amd_resident_steps(g.ptr, p.ptr, 2, 1)
+        lp = kernel_profile(lib, p); st = p.stats()
+        fac_ms = sum(k["ms"] / 2 for k in lp if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big"))
+        res.update(parallelism="single GPU", kernels_ms_per_step={k["name"]: round(k["ms"] / 2, 3) for k in lp},
+                   nnz_L=st["nnz_L"], sum_cj2=st["flops_factor"], fronts=st["n_fronts"], levels=st["n_levels"],
+                   max_front_rows=st["max_front_rows"], factor_tflops=st["flops_factor"] / (1e-3 * fac_ms) / 1e12)
+        lib.dll.aprilsam_amd_resident_end(g.ptr, p.ptr)
+    else:
+        from aprilsam_amd.shard import ShardedSolver
+        sol = ShardedSolver(lib, g, p, rank, world, backend=backend, device=device if backend == "nccl" else None)
+        res["setup_s_incl_ordering_symbolic_upload"] = time.perf_counter() - t0
+        chi = [sol.chi2()]
+        sol.iterate(1)                                  # first iteration: also opens the point-to-point channels
+        chi.append(sol.chi2())
+        barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sol.iterate(iters)
+        torch.cuda.synchronize(); barrier()
+        dt = sync_all(time.perf_counter() - t1)
+        chi.append(sol.chi2())
+        owned = int((sol.owner == rank).sum())
+        res.update(parallelism=f"nested-dissection subtree shards x{world}, exchange backend {backend}",
+                   fronts=int(sol.n_fronts), fronts_owned_by_rank0=owned, schur_slabs_exchanged=int(len(sol.xfer)),
+                   separator_broadcasts=int(len(sol.bcast)), comm_bytes_per_iteration=sol.comm_bytes_per_iteration())
+        sol.close()
+    res.update(ms_per_step=1e3 * dt / iters, timed_iterations=iters, chi2=chi)
+    if K == 1000 and iters == 2:
+        res["chi2_relerr_vs_single_gpu"] = [abs(a - b) / b for a, b in zip(chi, LATTICE1M_CHI2)]
+    p.destroy(); g.destroy()
+    return res
+
+
 def aggregate_value(world, steps, max_dt):
     """whole-job throughput of `world` independent replicas: GN iterations / s"""
     return world * steps / max_dt
@@ -115,16 +172,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lattice", action="store_true")
     ap.add_argument("--no-inc", action="store_true")
+    ap.add_argument("--lattice1m-k", type=int, default=1000, help="side of the config-5 lattice (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the driver's multi-GPU runs) | gloo (functional test, host staging)")
+    ap.add_argument("--one-gpu", action="store_true", help="test mode: every rank uses cuda:0")
     a = ap.parse_args()
 
     import torch
     import __graft_entry__ as ge
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if a.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if rank == 0:
         ge.build()
     torch.cuda.set_device(local)
-    barrier, sync_all = setup_dist(world, "nccl", torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    barrier, sync_all = setup_dist(world, a.backend, device if a.backend == "nccl" else torch.device("cpu"))
     from aprilsam_amd import datasets, host
     lib = host.SolverLib()
     lib.dll.aprilsam_amd_set_device(local)
@@ -259,11 +320,30 @@ def main():
         out["cpu_baseline"] = cpu_baseline(arrays)
         out["cpu_baseline"]["host"] = f"{os.cpu_count()} logical cores visible; reference is single-threaded"
         out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    if a.lattice1m_k > 0 and not a.no_lattice:
+        # config 5.  Every rank takes part when world > 1; the headline line must survive a hang of the exchange, so a
+        # watchdog prints it (rank 0) and ends the process if the extra does not come back in time.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["lattice1m"] = {"error": "watchdog: sharded solve did not finish in 420 s", "n_gpus": world}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(420.0, give_up); dog.daemon = True; dog.start()
+        try:
+            out["lattice1m"] = lattice1m(lib, rank, world, device, a.backend, barrier, sync_all, K=a.lattice1m_k)
+        except Exception as e:
+            out["lattice1m"] = {"error": repr(e), "n_gpus": world}
+        dog.cancel()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
-        dist.barrier(); dist.destroy_process_group()
+        try:
+            dist.barrier(); dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":
