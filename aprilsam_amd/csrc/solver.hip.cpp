@@ -1248,8 +1248,8 @@ int debug_front_times(const april_graph_cholesky_param_t *param, long long *out,
 // mapping: the root owns the rank range [0, world); a front with range [lo, hi) is owned by rank lo and hands the
 // halves [lo, mid) / [mid, hi) to its children, greedily balanced by subtree flops; ranges of size 1 make a whole
 // subtree local.  Per Gauss-Newton iteration the only data crossing ranks are
-//   * up:   the Schur update block of a front whose parent lives on another rank (one contiguous slab of its
-//           frontal array: columns 3*nsb.. end), sent point-to-point to the parent's owner,
+//   * up:   the Schur update block of a front whose parent lives on another rank (the lower trapezoid of columns
+//           3*nsb.. end of its frontal array, packed by k_pack_update), sent point-to-point to the parent's owner,
 //   * down: the solved x of the "top" fronts (range > 1 rank), a few thousand doubles each, broadcast.
 // The library only provides the per-level compute steps and the slab copies; the exchange itself is done by the
 // host driver with RCCL through torch.distributed (aprilsam_amd/shard.py) — one process per GPU.
@@ -1336,7 +1336,7 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
         const int par = P.f_parent[t];
         if (par >= 0 && S.owner[par] != S.owner[t]) {
             const long long R = P.rows(t), C = P.cols(t), ns = 3ll * P.f_nsb[t];
-            const long long v[6] = { P.f_level[t], t, S.owner[t], S.owner[par], P.f_off[t] + ns * R, (C - ns) * R };
+            const long long v[6] = { P.f_level[t], t, S.owner[t], S.owner[par], P.f_off[t], upd_packed_offset((int)R, (int)ns, (int)C) };
             S.xfer.insert(S.xfer.end(), v, v + 6);
         }
         if (S.top[t]) { const long long v[5] = { P.f_level[t], t, S.owner[t], P.f_first[t], P.f_nsb[t] }; S.bcast.insert(S.bcast.end(), v, v + 5); }
@@ -1402,6 +1402,16 @@ int shard_copy(april_graph_t *g, april_graph_cholesky_param_t *param, int kind, 
     if (ic == g_ctx.end()) return -1;
     Context &c = *ic->second;
     GraphPack &gp = pack_for(g);
+    if (kind == 2) {         // packed Schur update of front `offset`; buf must be a device pointer
+        const Plan &P = c.plan;
+        const int t = (int)offset;
+        if (t < 0 || t >= P.nF) return -1;
+        const int R = P.rows(t), C = P.cols(t), ns = 3 * P.f_nsb[t];
+        if (count != upd_packed_offset(R, ns, C)) return -2;
+        if (C > ns) hipLaunchKernelGGL(k_pack_update, dim3(C - ns), dim3(TPB), 0, gp.stream, c.d_pool.p + P.f_off[t], R, ns, (double *)buf, dir);
+        HIPCHECK(hipStreamSynchronize(gp.stream));
+        return 0;
+    }
     double *p = (kind == 0 ? c.d_pool.p : c.d_x.p) + offset;
     HIPCHECK(hipMemcpyAsync(dir == 0 ? buf : (void *)p, dir == 0 ? (void *)p : buf, (size_t)count * 8, hipMemcpyDefault, gp.stream));
     HIPCHECK(hipStreamSynchronize(gp.stream));

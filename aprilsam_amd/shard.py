@@ -4,7 +4,8 @@ RCCL over xGMI on the 8-GPU node; "gloo" with host staging in the tests, where t
 The library (include/aprilsam_amd.h, aprilsam_amd_shard_*) owns the plan, the ownership map and every kernel;
 this module only sequences the per-level steps and moves the two kinds of data that cross ranks:
 
-  up   — the Schur update slab of a front whose parent lives on another rank: send/recv, point to point
+  up   — the Schur update of a front whose parent lives on another rank, packed to the lower trapezoid the
+         parent's assembly reads (k_pack_update): send/recv, point to point
   down — the solved x of the top fronts (a few thousand doubles each): broadcast
 
 There is no all-reduce on the data path; chi^2 (outside the timed region) is one scalar all-reduce.
@@ -42,7 +43,10 @@ class ShardedSolver:
         self.up = [self.xfer[self.xfer[:, 0] == l] for l in range(self.n_levels)]
         self.down = [self.bcast[self.bcast[:, 0] == l] for l in range(self.n_levels)]
         nmax = int(max([1] + [int(r[5]) for r in self.xfer] + [3 * int(r[4]) for r in self.bcast]))
-        self.buf = torch.empty(nmax, dtype=torch.float64, device=self.dev)
+        # dbuf: device buffer the library packs into / unpacks from; buf: what torch.distributed moves (the same
+        # tensor with RCCL, a host mirror with gloo)
+        self.dbuf = torch.empty(nmax, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        self.buf = self.dbuf if self.on_gpu else torch.empty(nmax, dtype=torch.float64, device="cpu")
 
     def _info(self, what):
         n = self.lib.dll.aprilsam_amd_shard_info(self._p, what, None, 0)
@@ -56,7 +60,15 @@ class ShardedSolver:
             raise RuntimeError(f"shard_step({op},{arg}) rc={rc}")
 
     def _copy(self, kind, off, cnt, to_lib):
-        self.lib.dll.aprilsam_amd_shard_copy(self._g, self._p, kind, int(off), int(cnt), C.c_void_p(self.buf.data_ptr()), 1 if to_lib else 0)
+        """kind 2: packed Schur update of front `off`; kind 1: x at elimination offset `off`.  Synchronous."""
+        cnt = int(cnt)
+        if to_lib and not self.on_gpu:
+            self.dbuf[:cnt].copy_(self.buf[:cnt]); self.torch.cuda.synchronize()
+        rc = self.lib.dll.aprilsam_amd_shard_copy(self._g, self._p, kind, int(off), cnt, C.c_void_p(self.dbuf.data_ptr()), 1 if to_lib else 0)
+        if rc != 0:
+            raise RuntimeError(f"shard_copy(kind={kind}) rc={rc}")
+        if not to_lib and not self.on_gpu:
+            self.buf[:cnt].copy_(self.dbuf[:cnt])
 
     def iterate(self, n=1):
         dist = self.dist
@@ -66,11 +78,11 @@ class ShardedSolver:
                 self._step(1, l)
                 for _, front, src, dst, off, cnt in self.up[l]:
                     if self.rank == src:
-                        self._copy(0, off, cnt, False)
+                        self._copy(2, front, cnt, False)
                         dist.send(self.buf[:cnt], dst=int(dst))
                     elif self.rank == dst:
                         dist.recv(self.buf[:cnt], src=int(src))
-                        self._copy(0, off, cnt, True)
+                        self._copy(2, front, cnt, True)
             for l in range(self.n_levels - 1, -1, -1):
                 self._step(2, l)
                 for _, front, owner, first, nsb in self.down[l]:

@@ -227,15 +227,17 @@ int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, doubl
  * Every rank calls shard_begin with the same graph: identical plans, fronts split over ranks by proportional
  * mapping of the assembly tree.  One Gauss-Newton iteration = shard_step(op 0) ; for each level l ascending
  * { shard_step(1, l) ; transfers "up" of level l } ; for each level l descending { shard_step(2, l) ;
- * broadcasts "down" of level l } ; shard_step(3).  The exchanges (RCCL send/recv of one contiguous slab per
+ * broadcasts "down" of level l } ; shard_step(3).  The exchanges (RCCL send/recv of one packed Schur update per
  * transfer, broadcast of a few thousand doubles per top front) are issued by the host driver — see
  * aprilsam_amd/shard.py — between library calls; shard_copy moves the slabs between the library's HBM and the
  * driver's communication buffers.
- *   shard_info what: 0 -> {levels, fronts, nodes}; 1 -> transfers {level, front, src, dst, pool offset, count} (doubles);
+ *   shard_info what: 0 -> {levels, fronts, nodes}; 1 -> transfers {level, front, src, dst, pool offset, packed count} (doubles);
  *                    2 -> broadcasts {level, front, owner, first position, blocks}; 3 -> owner rank per front
  *   shard_step op  : 0 relinearise + linearise owned factors, 1 factor level arg, 2 back-substitute level arg,
  *                    3 state update, 4 synchronise (returns -2 on a non-positive pivot)
- *   shard_copy kind: 0 front pool, 1 solution vector x (offsets/counts in doubles); dir 0 library -> buf, 1 buf -> library */
+ *   shard_copy kind: 0 front pool, 1 solution vector x (offsets/counts in doubles), 2 packed Schur update of front
+ *                    `offset` (lower trapezoid of its update columns incl. the rhs row; buf must be DEVICE memory and
+ *                    count the packed count of shard_info); dir 0 library -> buf, 1 buf -> library */
 int       aprilsam_amd_shard_begin(april_graph_t *graph, april_graph_cholesky_param_t *param, int rank, int world);
 long long aprilsam_amd_shard_info(const april_graph_cholesky_param_t *param, int what, long long *out, long long cap);
 int       aprilsam_amd_shard_step(april_graph_t *graph, april_graph_cholesky_param_t *param, int op, int arg);
