@@ -61,6 +61,9 @@ static void load_env_options() {
         v = g_opt.trust_factor_cache; envd("APRILSAM_AMD_TRUST_FACTOR_CACHE", &v); g_opt.trust_factor_cache = (int)v;
         v = g_opt.small_lds_kb; envd("APRILSAM_AMD_SMALL_LDS_KB", &v); g_opt.small_lds_kb = (int)v;
         v = g_opt.medium_lds_kb; envd("APRILSAM_AMD_MEDIUM_LDS_KB", &v); g_opt.medium_lds_kb = (int)v;
+        v = g_opt.syrk128_rows; envd("APRILSAM_AMD_SYRK128_ROWS", &v); g_opt.syrk128_rows = (int)v;
+        v = g_opt.panel_mode; envd("APRILSAM_AMD_PANEL_MODE", &v); g_opt.panel_mode = (int)v;
+        v = g_opt.small_threads; envd("APRILSAM_AMD_SMALL_THREADS", &v); g_opt.small_threads = (int)v;
         v = g_opt.inc_fast; envd("APRILSAM_AMD_INC_FAST", &v); g_opt.inc_fast = (int)v;
     });
 }
@@ -224,7 +227,7 @@ static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp) {
 // ------------------------------------------------------------------------------------------------------
 enum { K_LINEARIZE = 0, K_FRONT_SMALL, K_FRONT_MEDIUM, K_ASSEMBLE_BIG, K_DIAG_BIG, K_PANEL_BIG, K_SYRK_BIG, K_BACKSOLVE, K_UPDATE, NKERN };
 static const char *const KNAMES[NKERN] = { "k_linearize", "k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big", "k_backsolve", "k_update_states" };
-struct Launch { int list_off, pre_off, n, grid; bool single = false; };   // single: every front has exactly one work item     // offsets into the int launch-table buffer
+struct Launch { int list_off, pre_off, n, grid; bool single = false; int tile = TILE; };   // single: every front has exactly one work item     // offsets into the int launch-table buffer
 
 struct LevelPlan {
     int small_off = 0, n_small = 0; size_t small_lds = 0;      // fronts handled by k_front_small
@@ -345,7 +348,9 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
         const int R = rows(t), C = cols(t);
         maxm = std::max<size_t>(maxm, C);
         const size_t lds_s = small_front_lds(R, C), lds_m = medium_front_lds(R);
+        const size_t lds_p = panel_front_lds(R, 3 * nsb_of(t));
         if (lds_s <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); }
+        else if (g_opt.panel_mode && lds_p <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_p); }   // k_front_small, panel mode
         else if (lds_m <= med_max) { med.push_back(t); L.med_lds = std::max(L.med_lds, lds_m); }
         else { big.push_back(t); L.asm_lds = std::max(L.asm_lds, big_scratch_bytes(R)); }
     }
@@ -379,7 +384,12 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
         L.syrk.push_back(make(nact, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), sidx, sidx + 1, 0); }));
         if ((sidx + 1) % OBP == 0 || sidx + 1 == steps) {
             const int s_lo = sidx / OBP * OBP;
-            L.syrkw.push_back(make(active(s_lo), [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, sidx + 1, 1); }));
+            // wide trailing matrices go to the LDS-staged 128 x 128 kernel (decided per launch on the largest front)
+            int span = 0;
+            for (int i = 0; i < active(s_lo); i++) { SyrkRange r = syrk_range(rows(big[i]), cols(big[i]), 3 * nsb_of(big[i]), s_lo, sidx + 1, 1); if (r.ntr > 0) span = std::max(span, rows(big[i]) - 2 - r.col_lo); }
+            const int tile = span >= g_opt.syrk128_rows ? TILE2 : TILE;
+            L.syrkw.push_back(make(active(s_lo), [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, sidx + 1, 1, tile); }));
+            L.syrkw.back().tile = tile;
         } else {
             L.syrkw.push_back(Launch{ 0, 0, 0, 0, false });
         }
@@ -427,6 +437,7 @@ static void upload_plan(Context &c, hipStream_t s) {
     DevPlan &d = c.dp;
     d.nF = P.nF;
     d.fd = c.d_fd.p; d.dest = c.d_dest.p; d.child = c.d_child.p;
+    d.small_lds_limit = (long long)g_opt.small_lds_kb * 1024;
     d.f_rows = c.d_i32.p; d.f_rel = c.d_i32.p; d.slot_blk = c.d_i32.p + o_sb; d.slot_rhs = c.d_i32.p + o_sr; d.src_idx = c.d_i32.p;
     c.inc.o_rows = (long long)o_rows; c.inc.o_rel = (long long)o_rel;
     d.lambda = c.d_lambda.p;
@@ -465,7 +476,9 @@ static void upload_plan(Context &c, hipStream_t s) {
 static void set_small_attr() {
     static std::once_flag once;
     std::call_once(once, [] {
-        HIPCHECK(hipFuncSetAttribute((const void *)k_front_small, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_medium, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_assemble_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -473,6 +486,14 @@ static void set_small_attr() {
 }
 
 // kernels of one level of the factorisation (small LDS fronts, medium, big multi-workgroup path)
+// k_front_small with the configured workgroup size (option small_threads: 256 / 512 / 1024)
+static void launch_front_small(Context &c, const LevelPlan &L, hipStream_t s) {
+    const int nt = g_opt.small_threads;
+    if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
+    else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
+    else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
+}
+
 // panel steps of the big fronts of one level: per NB-column panel {diagonal block, row solves, narrow update};
 // after every OBP panels one wide update with K = OBP * NB (kernels.hip.h: syrk_range)
 template <class Tic, class Toc>
@@ -498,7 +519,10 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
         }
         if (sw.grid > 0) {
             tic(K_SYRK_BIG);
-            hipLaunchKernelGGL(k_syrk_big, dim3(sw.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sw.list_off, c.d_tab.p + sw.pre_off, sw.n, (int)k / OBP * OBP, (int)k + 1, 1, c.d_pool.p);
+            if (sw.tile == TILE2)
+                hipLaunchKernelGGL(k_syrk_big128, dim3(sw.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sw.list_off, c.d_tab.p + sw.pre_off, sw.n, (int)k / OBP * OBP, (int)k + 1, 1, c.d_pool.p);
+            else
+                hipLaunchKernelGGL(k_syrk_big, dim3(sw.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sw.list_off, c.d_tab.p + sw.pre_off, sw.n, (int)k / OBP * OBP, (int)k + 1, 1, c.d_pool.p);
             toc();
         }
     }
@@ -508,7 +532,7 @@ template <class Tic, class Toc>
 static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc) {
     if (L.n_small) {
         tic(K_FRONT_SMALL);
-        hipLaunchKernelGGL(k_front_small, dim3(L.n_small), dim3(TPB), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
+        launch_front_small(c, L, s);
         toc();
     }
     if (L.n_med) {
@@ -853,7 +877,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     for (int l = 0; l <= I.nLev0; l++) {
         if (lev_dirty[l].empty()) continue;
         const LevelPlan &L = dl[l];
-        if (L.n_small) hipLaunchKernelGGL(k_front_small, dim3(L.n_small), dim3(TPB), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
+        if (L.n_small) launch_front_small(c, L, s);
         if (L.n_med) hipLaunchKernelGGL(k_front_medium, dim3(L.n_med), dim3(TPB_MED), L.med_lds, s, c.dp, c.d_tab.p + L.med_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
         if (L.n_big) {
             hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
@@ -1213,7 +1237,8 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
         const double ns = 3.0 * P.f_nsb[t], nu = 3.0 * P.f_nub[t], R = P.rows(t), C = P.cols(t);
         double fl = 0;                                          // sum_j c_j^2 over this front's columns (+ rhs row)
         for (int q = 0; q < (int)ns; q++) { double cj = (ns - q) + nu + 1; fl += cj * cj; }
-        const bool small = small_front_lds((int)R, (int)C) <= small_max, medium = !small && medium_front_lds((int)R) <= med_max;
+        const bool small = small_front_lds((int)R, (int)C) <= small_max || (g_opt.panel_mode && panel_front_lds((int)R, (int)ns) <= small_max);
+        const bool medium = !small && medium_front_lds((int)R) <= med_max;
         // algorithmic bytes of a front: its L panel + update block written once, children's updates read once
         const double by = 8.0 * (ns * (ns + 1) / 2 + (nu + 1) * ns + (nu + 1) * (nu + 2) / 2);
         if (small) { flops[K_FRONT_SMALL] += fl; bytes[K_FRONT_SMALL] += by; }
@@ -1456,6 +1481,9 @@ int api_set_option(const char *name, double v) {
     else if (k == "trust_factor_cache") g_opt.trust_factor_cache = (int)v;
     else if (k == "small_lds_kb") g_opt.small_lds_kb = (int)v;
     else if (k == "medium_lds_kb") g_opt.medium_lds_kb = (int)v;
+    else if (k == "syrk128_rows") g_opt.syrk128_rows = (int)v;
+    else if (k == "panel_mode") g_opt.panel_mode = (int)v;
+    else if (k == "small_threads") g_opt.small_threads = (int)v;
     else if (k == "inc_fast") g_opt.inc_fast = (int)v;
     else return -1;
     return 0;
