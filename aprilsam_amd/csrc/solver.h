@@ -15,7 +15,6 @@ struct Options {
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
     int small_threads = 512;      // workgroup size of k_front_small (256 / 512 / 1024)
     int panel_mode = 1;           // fronts too large for LDS whose own columns fit run in k_front_small's panel mode
-    int medium_lds_kb = 0;        // fronts whose 32-column panel fits run in the single-workgroup L2 kernel (0 = off)
 };
 extern Options g_opt;
 

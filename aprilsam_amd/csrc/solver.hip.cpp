@@ -60,7 +60,6 @@ static void load_env_options() {
         v = g_opt.device_timing; envd("APRILSAM_AMD_DEVICE_TIMING", &v); g_opt.device_timing = (int)v;
         v = g_opt.trust_factor_cache; envd("APRILSAM_AMD_TRUST_FACTOR_CACHE", &v); g_opt.trust_factor_cache = (int)v;
         v = g_opt.small_lds_kb; envd("APRILSAM_AMD_SMALL_LDS_KB", &v); g_opt.small_lds_kb = (int)v;
-        v = g_opt.medium_lds_kb; envd("APRILSAM_AMD_MEDIUM_LDS_KB", &v); g_opt.medium_lds_kb = (int)v;
         v = g_opt.syrk128_rows; envd("APRILSAM_AMD_SYRK128_ROWS", &v); g_opt.syrk128_rows = (int)v;
         v = g_opt.panel_mode; envd("APRILSAM_AMD_PANEL_MODE", &v); g_opt.panel_mode = (int)v;
         v = g_opt.small_threads; envd("APRILSAM_AMD_SMALL_THREADS", &v); g_opt.small_threads = (int)v;
@@ -225,13 +224,12 @@ static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp) {
 // ------------------------------------------------------------------------------------------------------
 // solver context — one per april_graph_cholesky_param_t pointer
 // ------------------------------------------------------------------------------------------------------
-enum { K_LINEARIZE = 0, K_FRONT_SMALL, K_FRONT_MEDIUM, K_ASSEMBLE_BIG, K_DIAG_BIG, K_PANEL_BIG, K_SYRK_BIG, K_BACKSOLVE, K_UPDATE, NKERN };
-static const char *const KNAMES[NKERN] = { "k_linearize", "k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big", "k_backsolve", "k_update_states" };
+enum { K_LINEARIZE = 0, K_FRONT_SMALL, K_ASSEMBLE_BIG, K_DIAG_BIG, K_PANEL_BIG, K_SYRK_BIG, K_BACKSOLVE, K_UPDATE, NKERN };
+static const char *const KNAMES[NKERN] = { "k_linearize", "k_front_small", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big", "k_backsolve", "k_update_states" };
 struct Launch { int list_off, pre_off, n, grid; bool single = false; int tile = TILE; };   // single: every front has exactly one work item     // offsets into the int launch-table buffer
 
 struct LevelPlan {
     int small_off = 0, n_small = 0; size_t small_lds = 0;      // fronts handled by k_front_small
-    int med_off = 0, n_med = 0; size_t med_lds = 0;            // fronts handled by k_front_medium
     int n_big = 0; size_t asm_lds = 0;
     Launch asm_big{};                                          // k_assemble_big
     std::vector<Launch> panel, syrk, syrkw;                    // per panel step: diag+panel, narrow update, wide update (grid 0 unless the step closes an outer block)
@@ -334,12 +332,12 @@ bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out)
 constexpr int INC_NODES = 4096, INC_FACT = 16384, INC_I32 = 4 << 20, INC_DEST = 1 << 20, INC_CHILD = 1 << 18, INC_TAB = 1 << 20;
 constexpr long long INC_POOL_MIN = 64ll << 20;            // doubles (512 MB)
 
-// classify the fronts of one level (small / medium / big) and append their launch tables to `tab`
+// classify the fronts of one level (small / big) and append their launch tables to `tab`
 template <class Dims>
 static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int> &tab, Dims dims) {
-    const size_t small_max = (size_t)g_opt.small_lds_kb * 1024, med_max = (size_t)g_opt.medium_lds_kb * 1024;
+    const size_t small_max = (size_t)g_opt.small_lds_kb * 1024;
     L = LevelPlan();
-    std::vector<int> small, med, big;
+    std::vector<int> small, big;
     size_t maxm = 0;
     auto rows = [&](int t) { int a, b; dims(t, &a, &b); return 3 * (a + b + 1); };
     auto cols = [&](int t) { int a, b; dims(t, &a, &b); return 3 * (a + b); };
@@ -347,12 +345,11 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     for (int t : fronts) {
         const int R = rows(t), C = cols(t);
         maxm = std::max<size_t>(maxm, C);
-        const size_t lds_s = small_front_lds(R, C), lds_m = medium_front_lds(R);
+        const size_t lds_s = small_front_lds(R, C);
         const size_t lds_p = panel_front_lds(R, 3 * nsb_of(t));
         if (lds_s <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); }
         else if (g_opt.panel_mode && lds_p <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_p); }   // k_front_small, panel mode
-        else if (lds_m <= med_max) { med.push_back(t); L.med_lds = std::max(L.med_lds, lds_m); }
-        else { big.push_back(t); L.asm_lds = std::max(L.asm_lds, big_scratch_bytes(R)); }
+        else big.push_back(t);
     }
     // longest-processing-time first: the widest fronts of a level start first
     std::sort(small.begin(), small.end(), [&](int a, int b) { int ra = rows(a), rb = rows(b); return ra != rb ? ra > rb : a < b; });
@@ -361,8 +358,6 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     L.solve_lds = (maxm + NB + 8) * 8;
     L.small_off = (int)tab.size(); L.n_small = (int)small.size();
     tab.insert(tab.end(), small.begin(), small.end());
-    L.med_off = (int)tab.size(); L.n_med = (int)med.size();
-    tab.insert(tab.end(), med.begin(), med.end());
     L.n_big = (int)big.size();
     if (big.empty()) return;
     std::sort(big.begin(), big.end(), [&](int a, int b) { return nsb_of(a) != nsb_of(b) ? nsb_of(a) > nsb_of(b) : a < b; });
@@ -479,13 +474,11 @@ static void set_small_attr() {
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHECK(hipFuncSetAttribute((const void *)k_front_medium, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHECK(hipFuncSetAttribute((const void *)k_assemble_big, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
 }
 
-// kernels of one level of the factorisation (small LDS fronts, medium, big multi-workgroup path)
+// kernels of one level of the factorisation (small LDS fronts, big multi-workgroup path)
 // k_front_small with the configured workgroup size (option small_threads: 256 / 512 / 1024)
 static void launch_front_small(Context &c, const LevelPlan &L, hipStream_t s) {
     const int nt = g_opt.small_threads;
@@ -533,11 +526,6 @@ static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, 
     if (L.n_small) {
         tic(K_FRONT_SMALL);
         launch_front_small(c, L, s);
-        toc();
-    }
-    if (L.n_med) {
-        tic(K_FRONT_MEDIUM);
-        hipLaunchKernelGGL(k_front_medium, dim3(L.n_med), dim3(TPB_MED), L.med_lds, s, c.dp, c.d_tab.p + L.med_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
         toc();
     }
     if (L.n_big) {
@@ -841,7 +829,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         if (lev_dirty[l].empty()) continue;
         LevelPlan &L = dl[l];
         const int sh = (int)I.tab_used;
-        L.all_off += sh; L.small_off += sh; L.med_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
+        L.all_off += sh; L.small_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
         for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
@@ -878,7 +866,6 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         if (lev_dirty[l].empty()) continue;
         const LevelPlan &L = dl[l];
         if (L.n_small) launch_front_small(c, L, s);
-        if (L.n_med) hipLaunchKernelGGL(k_front_medium, dim3(L.n_med), dim3(TPB_MED), L.med_lds, s, c.dp, c.d_tab.p + L.med_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
         if (L.n_big) {
             hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
                                c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
@@ -1232,17 +1219,15 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
     Context &c = *it->second;
     const Plan &P = c.plan;
     for (int k = 0; k < NKERN; k++) { ms[k] = c.k_ms[k]; calls[k] = c.k_calls[k]; flops[k] = 0; bytes[k] = 0; if (names) names[k] = KNAMES[k]; }
-    const size_t small_max = (size_t)g_opt.small_lds_kb * 1024, med_max = (size_t)g_opt.medium_lds_kb * 1024;
+    const size_t small_max = (size_t)g_opt.small_lds_kb * 1024;
     for (int t = 0; t < P.nF; t++) {
         const double ns = 3.0 * P.f_nsb[t], nu = 3.0 * P.f_nub[t], R = P.rows(t), C = P.cols(t);
         double fl = 0;                                          // sum_j c_j^2 over this front's columns (+ rhs row)
         for (int q = 0; q < (int)ns; q++) { double cj = (ns - q) + nu + 1; fl += cj * cj; }
         const bool small = small_front_lds((int)R, (int)C) <= small_max || (g_opt.panel_mode && panel_front_lds((int)R, (int)ns) <= small_max);
-        const bool medium = !small && medium_front_lds((int)R) <= med_max;
         // algorithmic bytes of a front: its L panel + update block written once, children's updates read once
         const double by = 8.0 * (ns * (ns + 1) / 2 + (nu + 1) * ns + (nu + 1) * (nu + 2) / 2);
         if (small) { flops[K_FRONT_SMALL] += fl; bytes[K_FRONT_SMALL] += by; }
-        else if (medium) { flops[K_FRONT_MEDIUM] += fl; bytes[K_FRONT_MEDIUM] += by; }
         else { flops[K_SYRK_BIG] += fl; bytes[K_SYRK_BIG] += by; }
         bytes[K_BACKSOLVE] += 8.0 * (ns * (ns + 1) / 2 + nu * ns) + 16.0 * (ns + nu);
         flops[K_BACKSOLVE] += 2.0 * (ns * (ns + 1) / 2 + nu * ns);
@@ -1343,7 +1328,7 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
         build_level(S.levels[l], fr, tab, [&](int t, int *nsb, int *nub) { *nsb = P.f_nsb[t]; *nub = P.f_nub[t]; });
         LevelPlan &L = S.levels[l];
         const int sh = (int)c.inc.tab_used;
-        L.all_off += sh; L.small_off += sh; L.med_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
+        L.all_off += sh; L.small_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
         for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
@@ -1480,7 +1465,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "device_timing") g_opt.device_timing = (int)v;
     else if (k == "trust_factor_cache") g_opt.trust_factor_cache = (int)v;
     else if (k == "small_lds_kb") g_opt.small_lds_kb = (int)v;
-    else if (k == "medium_lds_kb") g_opt.medium_lds_kb = (int)v;
+    else if (k == "medium_lds_kb") {}                 // accepted for compatibility: the single-workgroup L2 kernel is gone (panel mode)
     else if (k == "syrk128_rows") g_opt.syrk128_rows = (int)v;
     else if (k == "panel_mode") g_opt.panel_mode = (int)v;
     else if (k == "small_threads") g_opt.small_threads = (int)v;
