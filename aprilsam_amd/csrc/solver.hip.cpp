@@ -332,6 +332,9 @@ bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out)
 constexpr int INC_NODES = 4096, INC_FACT = 16384, INC_I32 = 4 << 20, INC_DEST = 1 << 20, INC_CHILD = 1 << 18, INC_TAB = 1 << 20;
 constexpr long long INC_POOL_MIN = 64ll << 20;            // doubles (512 MB)
 
+// waves of a k_front_small workgroup (option small_threads)
+static int small_waves() { return g_opt.small_threads >= 1024 ? 16 : (g_opt.small_threads >= 512 ? 8 : 4); }
+
 // classify the fronts of one level (small / big) and append their launch tables to `tab`
 template <class Dims>
 static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int> &tab, Dims dims) {
@@ -345,8 +348,7 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     for (int t : fronts) {
         const int R = rows(t), C = cols(t);
         maxm = std::max<size_t>(maxm, C);
-        const size_t lds_s = small_front_lds(R, C);
-        const size_t lds_p = panel_front_lds(R, 3 * nsb_of(t));
+        const size_t lds_s = small_front_lds(R, C, small_waves()), lds_p = panel_front_lds(R, 3 * nsb_of(t), small_waves());
         if (lds_s <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); }
         else if (g_opt.panel_mode && lds_p <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_p); }   // k_front_small, panel mode
         else big.push_back(t);
@@ -1224,7 +1226,7 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
         const double ns = 3.0 * P.f_nsb[t], nu = 3.0 * P.f_nub[t], R = P.rows(t), C = P.cols(t);
         double fl = 0;                                          // sum_j c_j^2 over this front's columns (+ rhs row)
         for (int q = 0; q < (int)ns; q++) { double cj = (ns - q) + nu + 1; fl += cj * cj; }
-        const bool small = small_front_lds((int)R, (int)C) <= small_max || (g_opt.panel_mode && panel_front_lds((int)R, (int)ns) <= small_max);
+        const bool small = small_front_lds((int)R, (int)C, small_waves()) <= small_max || (g_opt.panel_mode && panel_front_lds((int)R, (int)ns, small_waves()) <= small_max);
         // algorithmic bytes of a front: its L panel + update block written once, children's updates read once
         const double by = 8.0 * (ns * (ns + 1) / 2 + (nu + 1) * ns + (nu + 1) * (nu + 2) / 2);
         if (small) { flops[K_FRONT_SMALL] += fl; bytes[K_FRONT_SMALL] += by; }
