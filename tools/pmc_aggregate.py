@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Aggregate the rocprofv3 csv files written by tools/profile_round.sh into the small files kept under profiles/:
+    <tag>_kernel_stats.csv          per-kernel totals of the M3500 bench command
+    <tag>_kernel_stats_lattice.csv  same for the 100k-lattice run
+    <tag>_pmc_hbm.json              FETCH_SIZE / WRITE_SIZE per kernel (raw KB, per dispatch)
+    <tag>_pmc_mfma.json             MFMA busy cycles / CU busy cycles / F64 MFMA ops per kernel (100k lattice)
+usage: pmc_aggregate.py <dir written by profile_round.sh> <tag>"""
+import csv, glob, json, os, re, shutil, sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+dst = os.path.join(src, "summary"); os.makedirs(dst, exist_ok=True)
+
+
+def find(sub, pat):
+    f = sorted(glob.glob(os.path.join(src, sub, "**", pat), recursive=True))
+    return f[0] if f else None
+
+
+def short(name):
+    m = re.search(r"(k_[a-z0-9_]+)", name)
+    return m.group(1) if m else name.split("(")[0][:48]
+
+
+def counters(sub):
+    f = find(sub, "*counter_collection.csv")
+    if not f:
+        return None
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            a = acc[row["Counter_Name"]][short(row["Kernel_Name"])]
+            a[0] += 1; a[1] += float(row["Counter_Value"])
+    return {c: {k: {"dispatches": v[0], "total": round(v[1], 1), "per_dispatch": round(v[1] / v[0], 2)} for k, v in ks.items()} for c, ks in acc.items()}
+
+
+for sub, out in (("stats", f"{tag}_kernel_stats.csv"), ("stats_lattice", f"{tag}_kernel_stats_lattice.csv")):
+    f = find(sub, "*kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(dst, out)); print("wrote", out)
+hbm = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    r = counters("pmc_" + c)
+    if r and c in r:
+        hbm[c] = {k: {"dispatches": v["dispatches"], "total_kb": v["total"], "kb_per_dispatch": v["per_dispatch"]} for k, v in r[c].items()}
+if hbm:
+    json.dump({"command": "APRILSAM_AMD_USE_GRAPH=0 rocprofv3 --pmc <COUNTER> --output-format csv -- python bench.py --steps 10 --warmup 2 --no-lattice "
+                          "--no-inc --no-cpu-baseline (one pass per counter, hipGraph replay off)",
+               "unit": "KB as reported by rocprofv3; MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 - "
+                       "values are RAW, bench.py applies the x2 to the read side", "counters": hbm},
+              open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
+    print("wrote", f"{tag}_pmc_hbm.json")
+m = counters("pmc_mfma")
+if m:
+    per = {}
+    for k in set().union(*[set(v) for v in m.values()]):
+        g = lambda c: m.get(c, {}).get(k, {}).get("total", 0.0)
+        busy, cu, ops = g("SQ_VALU_MFMA_BUSY_CYCLES"), g("SQ_BUSY_CU_CYCLES"), g("SQ_INSTS_VALU_MFMA_MOPS_F64")
+        per[k] = {"dispatches": m[next(iter(m))].get(k, {}).get("dispatches", 0), "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CU_CYCLES": cu,
+                  "SQ_INSTS_VALU_MFMA_MOPS_F64": ops, "GRBM_GUI_ACTIVE": g("GRBM_GUI_ACTIVE"),
+                  "mfma_busy_over_cu_busy": round(busy / cu, 4) if cu else None}
+    json.dump({"command": "APRILSAM_AMD_USE_GRAPH=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE "
+                          "-- python tools/lattice_big.py 316 2   (100k-pose lattice, config 4; sums over all dispatches of the run)",
+               "kernels": per}, open(os.path.join(dst, f"{tag}_pmc_mfma.json"), "w"), indent=1)
+    print("wrote", f"{tag}_pmc_mfma.json")

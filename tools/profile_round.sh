@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence of one round on the MI355X box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh r01
+# Outputs under gpurun_out/prof_<tag>/ ; tools/pmc_aggregate.py turns them into the files kept in profiles/.
+# Counter passes are separate runs (one --pmc set each, no trace domains besides the kernel trace), without hipGraph
+# replay (counter collection over graph replays does not terminate on ROCm 7.2) and each under its own timeout.
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 200 --warmup 10 --no-lattice --no-inc --no-cpu-baseline"
+SHORT="python $ROOT/bench.py --steps 10 --warmup 2 --no-lattice --no-inc --no-cpu-baseline"
+LAT="python $ROOT/tools/lattice_big.py 316 2"
+rocprofv3 -L > $OUT/counters_available.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  APRILSAM_AMD_USE_GRAPH=0 timeout 200 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- $SHORT > $OUT/pmc_$C.log 2>&1
+done
+# MFMA utilisation of the wide-supernode path: 100k lattice (config 4), counters per dispatch
+APRILSAM_AMD_USE_GRAPH=0 timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- $LAT > $OUT/pmc_mfma.log 2>&1
+APRILSAM_AMD_USE_GRAPH=0 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lattice -- $LAT > $OUT/stats_lattice.log 2>&1
+cd $ROOT
+python tools/pmc_aggregate.py $OUT $TAG > $OUT/aggregate.log 2>&1
+tail -5 $OUT/aggregate.log
