@@ -357,7 +357,7 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     std::sort(small.begin(), small.end(), [&](int a, int b) { int ra = rows(a), rb = rows(b); return ra != rb ? ra > rb : a < b; });
     L.all_off = (int)tab.size(); L.n_all = (int)fronts.size();
     tab.insert(tab.end(), fronts.begin(), fronts.end());
-    L.solve_lds = (maxm + NB + 8) * 8;
+    L.solve_lds = (maxm + NB + 8 + NB * (NB + 1)) * 8;
     L.small_off = (int)tab.size(); L.n_small = (int)small.size();
     tab.insert(tab.end(), small.begin(), small.end());
     L.n_big = (int)big.size();
@@ -835,7 +835,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
-        if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8) * 8);
+        if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
     }
     // ---- 4. uploads ------------------------------------------------------------------------------------------------
     if (!st_i32.empty()) HIPCHECK(hipMemcpyAsync(c.d_i32.p + I.i32_used, st_i32.data(), st_i32.size() * 4, hipMemcpyHostToDevice, s));
@@ -991,6 +991,17 @@ void batch_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
 // the relinearisation counter and the batch fall-back follow the reference exactly through the bookkeeping
 // model of refmodel.cpp (measured: on the poses it touches, the reference's result is the exact solution).
 // ------------------------------------------------------------------------------------------------------
+// APRILSAM_AMD_INC_PROFILE=1: host wall-clock split of the incremental steps, printed at process exit
+struct IncProf {
+    bool on = false; double acc[8] = { 0 }; long long n = 0;
+    IncProf() { const char *e = getenv("APRILSAM_AMD_INC_PROFILE"); on = e && *e == '1'; }
+    ~IncProf() {
+        if (on && n) fprintf(stderr, "aprilsam_amd inc profile over %lld steps (ms/step): pack %.4f model %.4f upload %.4f plan+enqueue %.4f d2h+sync %.4f writeback %.4f | total %.4f\n",
+                             n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5]) / n);
+    }
+};
+static IncProf g_incprof;
+
 void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0) return;          // aprilsam.c:380-381
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1006,9 +1017,12 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     pack_factors(gp, g);
     pack_states(gp, g, true);
     const int N = gp.N, F = gp.F;
+    const double tp1 = now_ms();
     if (!c.model.valid) c.model.batch(c.batch_nodes, c.batch_factors, gp.h_fa.p, gp.h_fb.p);      // lazily, after a batch step
     c.model.inc_begin(N, F, gp.h_fa.p, gp.h_fb.p);
+    const double tp2 = now_ms();
     upload_factors(gp);
+    const double tp3 = now_ms();
     // fast path: frozen base plan + TAIL front, only the dirty root paths are regenerated and re-factorised
     std::vector<RefModel::Visit> &visits = c.visits;
     c.model.plan_visit(visits);                      // structural: which poses the reference's solve_node touches
@@ -1023,10 +1037,12 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
         inc_prepare(c);
     }
     c.inc_F = F; c.inc_N = N;
+    const double tp4 = now_ms();
     HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
     HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
     HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, gp.stream));
     HIPCHECK(hipStreamSynchronize(gp.stream));
+    const double tp5 = now_ms();
     c.st.not_spd = c.h_bad.p[0] != 0;
     c.st.n_nodes = N; c.st.n_factors = F; c.st.symbolic_reused = reused;
     if (c.st.not_spd) {
@@ -1055,6 +1071,10 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     param->factor_num = F;
     const double step_ms = now_ms() - t0;
     c.st.ms_total = step_ms;
+    if (g_incprof.on) {
+        g_incprof.acc[0] += tp1 - t0; g_incprof.acc[1] += tp2 - tp1; g_incprof.acc[2] += tp3 - tp2; g_incprof.acc[3] += tp4 - tp3;
+        g_incprof.acc[4] += tp5 - tp4; g_incprof.acc[5] += now_ms() - tp5; g_incprof.n++;
+    }
     if (!g_opt.deterministic && step_ms > param->batch_time / 3) c.model.start_over = 0x7fffffff;    // aprilsam.c:557-559
     if (c.model.start_over > param->nthreshold) {                                                   // aprilsam.c:566-575
         const double b0 = now_ms();
