@@ -125,12 +125,15 @@ struct GraphPack {
     DBuf<double> d_z, d_W, d_state, d_lp, d_dx, d_chi2f, d_scalar;
     int F_on_device = 0;               // factors already uploaded
     int F_cap = 0;                     // device capacity (factors) of d_fa/d_fb/d_z/d_W/d_chi2f
+    // factors of foreign types, evaluated on the host through factor->eval: indices, 33 doubles each
+    // (Haa, Hab, Hbb, ga, gb), how many of them hold a current evaluation
+    std::vector<int> host_idx; HBuf<double> h_hostH; DBuf<double> d_hostH; DBuf<int> d_host_idx; int host_evaluated = 0;
     hipStream_t stream = nullptr;
     HBuf<double> h_scalar;
     void release() {
         h_fa.release(); h_fb.release(); h_z.release(); h_W.release(); h_state.release(); h_lp.release(); h_dx.release();
         d_fa.release(); d_fb.release(); d_z.release(); d_W.release(); d_state.release(); d_lp.release(); d_dx.release();
-        d_chi2f.release(); d_scalar.release(); h_scalar.release();
+        d_chi2f.release(); d_scalar.release(); h_scalar.release(); h_hostH.release(); d_hostH.release(); d_host_idx.release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -163,7 +166,7 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g) {
     int from = gp.F;
     bool valid = g_opt.trust_factor_cache && from <= F && (int)gp.fptr.size() == from &&
                  (from == 0 || memcmp(gp.fptr.data(), fs, sizeof(void *) * from) == 0);
-    if (!valid) { from = 0; gp.F_on_device = 0; }
+    if (!valid) { from = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; }
     gp.h_fa.need(F, true); gp.h_fb.need(F, true); gp.h_z.need((size_t)3 * F, true); gp.h_W.need((size_t)9 * F, true);
     gp.fptr.resize(F);
     const int N = zsize(g->nodes);
@@ -171,17 +174,25 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g) {
         const april_graph_factor_t *f = fs[i];
         gp.fptr[i] = f;
         int a = -1, b = -1;
+        bool host_eval = false;
         if (f->type == APRIL_GRAPH_FACTOR_XYT_TYPE && f->nnodes == 2) { a = f->nodes[0]; b = f->nodes[1]; }
         else if (f->type == APRIL_GRAPH_FACTOR_XYTPOS_TYPE && f->nnodes == 1) { a = f->nodes[0]; b = -1; }
-        else {
-            fprintf(stderr, "aprilsam_amd: FATAL: factor %d has type %d / %d nodes; only xyt (1) and xytpos (2) factors are "
-                            "evaluated on the device\n", i, f->type, f->nnodes);
+        else if ((f->nnodes == 1 || f->nnodes == 2) && f->eval) {     // any other type: the factor's own eval(), on the host
+            a = f->nodes[0]; b = f->nnodes == 2 ? f->nodes[1] : -1; host_eval = true;
+        } else {
+            fprintf(stderr, "aprilsam_amd: FATAL: factor %d has type %d / %d nodes; factors of foreign types are supported with one or "
+                            "two nodes and an eval() function pointer (aprilsam.h:110-122)\n", i, f->type, f->nnodes);
             abort();
         }
         if (a < 0 || a >= N || b >= N || a == b) { fprintf(stderr, "aprilsam_amd: FATAL: factor %d references node out of range\n", i); abort(); }
         gp.h_fa.p[i] = a; gp.h_fb.p[i] = b;
-        memcpy(gp.h_z.p + (size_t)3 * i, f->u.common.z, 24);
-        memcpy(gp.h_W.p + (size_t)9 * i, f->u.common.W->data, 72);
+        if (host_eval) {          // the device kernels see a null factor (W = 0) in its place; k_scatter_host fills its slots
+            memset(gp.h_z.p + (size_t)3 * i, 0, 24); memset(gp.h_W.p + (size_t)9 * i, 0, 72);
+            gp.host_idx.push_back(i);
+        } else {
+            memcpy(gp.h_z.p + (size_t)3 * i, f->u.common.z, 24);
+            memcpy(gp.h_W.p + (size_t)9 * i, f->u.common.W->data, 72);
+        }
     }
     gp.F = F;
 }
@@ -204,6 +215,50 @@ static void upload_factors(GraphPack &gp) {
     gp.F_on_device = F;
     gp.d_scalar.need(8); gp.h_scalar.need(8);
 }
+// evaluate the host factors [from, end) through their vtable (aprilsam.c:156 calls factor->eval the same way) and form
+// (J_a^T W) J_a, (J_a^T W) J_b, (J_b^T W) J_b, (J^T W) r in the reference's association (aprilsam.c:162-187)
+static double eval_host_factors(GraphPack &gp, april_graph_t *g, int from) {
+    const int nh = (int)gp.host_idx.size();
+    gp.h_hostH.need((size_t)33 * std::max(nh, 1), true);
+    april_graph_factor_t **fs = (april_graph_factor_t **)g->factors->data;
+    double chi2 = 0;
+    for (int k = from; k < nh; k++) {
+        april_graph_factor_t *f = fs[gp.host_idx[k]];
+        april_graph_factor_eval_t *e = f->eval(f, g, nullptr);
+        if (!e || !e->jacobians || !e->jacobians[0] || !e->W || !e->r) fatal("factor->eval returned an incomplete evaluation (aprilsam.h:75-89)");
+        const int L = e->length;
+        double *H = gp.h_hostH.p + (size_t)33 * k;
+        memset(H, 0, 33 * 8);
+        std::vector<double> JtW((size_t)3 * L);
+        for (int z0 = 0; z0 < f->nnodes; z0++) {
+            const matd_t *J0 = e->jacobians[z0];
+            if (!J0 || (int)J0->nrows != L || J0->ncols != 3 || (int)e->W->nrows != L || (int)e->W->ncols != L)
+                fatal("factor->eval: jacobians must be length x 3 and W length x length (3-DoF xyt nodes only, aprilsam.c:617)");
+            for (int i = 0; i < 3; i++)
+                for (int l = 0; l < L; l++) { double acc = 0; for (int m = 0; m < L; m++) acc += J0->data[m * 3 + i] * e->W->data[m * L + l]; JtW[(size_t)i * L + l] = acc; }
+            for (int z1 = z0; z1 < f->nnodes; z1++) {
+                const matd_t *J1 = e->jacobians[z1];
+                if (!J1) fatal("factor->eval: fewer jacobians than nodes");
+                double *B = H + (z0 == 0 ? (z1 == 0 ? 0 : 9) : 18);
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) { double acc = 0; for (int l = 0; l < L; l++) acc += JtW[(size_t)i * L + l] * J1->data[l * 3 + j]; B[i * 3 + j] = acc; }
+            }
+            double *gv = H + 27 + 3 * z0;
+            for (int i = 0; i < 3; i++) { double acc = 0; for (int l = 0; l < L; l++) acc += JtW[(size_t)i * L + l] * e->r[l]; gv[i] = acc; }
+        }
+        chi2 += e->chi2;
+        april_graph_factor_eval_destroy(e);
+    }
+    gp.host_evaluated = nh;
+    return chi2;
+}
+static void upload_host_index(GraphPack &gp) {
+    const int nh = (int)gp.host_idx.size();
+    if (!nh) return;
+    gp.d_host_idx.need(nh); gp.d_hostH.need((size_t)33 * nh);
+    HIPCHECK(hipMemcpyAsync(gp.d_host_idx.p, gp.host_idx.data(), (size_t)4 * nh, hipMemcpyHostToDevice, gp.stream));
+}
+
 // states (and l_points) of all nodes -> pinned host -> device
 static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp) {
     const int N = zsize(g->nodes);
@@ -560,6 +615,12 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     tic(K_LINEARIZE);
     hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                        gp.d_lp.p, unary_at_lp ? gp.d_lp.p : gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
+    if (!gp.host_idx.empty()) {         // host-evaluated factors: their blocks replace the null contributions written above
+        const int nh = (int)gp.host_idx.size();
+        HIPCHECK(hipMemcpyAsync(gp.d_hostH.p, gp.h_hostH.p, (size_t)33 * 8 * nh, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_scatter_host, dim3((nh + TPB - 1) / TPB), dim3(TPB), 0, s, nh, gp.d_host_idx.p, gp.d_hostH.p, gp.d_fb.p, c.d_swap.p,
+                           c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
+    }
     toc();
     if (ev) HIPCHECK(hipEventRecord(ev[1], s));
     for (int l = 0; l < P.nLevels; l++) enqueue_factor_level(c, c.levels[l], s, tic, toc);
@@ -592,7 +653,7 @@ static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp
     hipStream_t s = gp.stream;
     set_small_attr();
     if (timing && !c.have_events) { for (auto &e : c.ev) HIPCHECK(hipEventCreate(&e)); c.have_events = true; }
-    if (g_opt.use_graph && !timing && !unary_at_lp) {
+    if (g_opt.use_graph && !timing && !unary_at_lp && gp.host_idx.empty()) {   // (host-evaluated factors: staging buffers may move)
         if (!c.gexec || c.gexec_key != (const void *)gp.d_state.p) {
             if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
             hipGraph_t graph = nullptr;
@@ -912,6 +973,12 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     pack_factors(gp, g);
     pack_states(gp, g, false);
     const int N = gp.N, F = gp.F;
+    if (!gp.host_idx.empty()) {       // foreign factor types: their eval() reads the host objects, which the reference
+        april_graph_node_t **hn = (april_graph_node_t **)g->nodes->data;     // re-linearises first (aprilsam.c:131-135)
+        for (int i = 0; i < N; i++) memcpy(hn[i]->l_point, hn[i]->state, 24);
+        eval_host_factors(gp, g, 0);
+        upload_host_index(gp);
+    }
     const double t1 = now_ms();
     const bool reused = prepare_plan(c, gp, g);
     const double t2 = now_ms();
@@ -1022,12 +1089,16 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     c.model.inc_begin(N, F, gp.h_fa.p, gp.h_fb.p);
     const double tp2 = now_ms();
     upload_factors(gp);
+    if (!gp.host_idx.empty()) {       // new foreign factors are linearised now, at the host objects' current l_points
+        eval_host_factors(gp, g, gp.host_evaluated);     // (aprilsam.c:508-542); older ones keep their evaluation
+        upload_host_index(gp);
+    }
     const double tp3 = now_ms();
     // fast path: frozen base plan + TAIL front, only the dirty root paths are regenerated and re-factorised
     std::vector<RefModel::Visit> &visits = c.visits;
     c.model.plan_visit(visits);                      // structural: which poses the reference's solve_node touches
     const bool partial = c.model.naffected <= 5;     // aprilsam.c:755: otherwise the whole tree is walked
-    bool reused = g_opt.inc_fast && inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, partial ? &visits : nullptr);
+    bool reused = g_opt.inc_fast && gp.host_idx.empty() && inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, partial ? &visits : nullptr);
     if (!reused) {                // the step does not fit the frozen structure (or slack ran out): full re-plan
         prepare_plan(c, gp, g);
         c.h_lambda.assign(N, 0.0);
@@ -1122,7 +1193,16 @@ double graph_chi2(april_graph_t *g) {
     pack_factors(gp, g);
     pack_states(gp, g, false);
     upload_factors(gp);
-    return device_chi2(gp);
+    double chi2 = device_chi2(gp);
+    if (!gp.host_idx.empty()) {       // april_graph.c:90-93: factors other than xyt contribute eval()->chi2
+        april_graph_factor_t **fs = (april_graph_factor_t **)g->factors->data;
+        for (int idx : gp.host_idx) {
+            april_graph_factor_eval_t *e = fs[idx]->eval(fs[idx], g, nullptr);
+            chi2 += e->chi2;
+            april_graph_factor_eval_destroy(e);
+        }
+    }
+    return chi2;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1135,6 +1215,7 @@ int resident_begin(april_graph_t *g, april_graph_cholesky_param_t *param) {
     Context &c = ctx_for(param);
     GraphPack &gp = pack_for(g);
     pack_factors(gp, g);
+    if (!gp.host_idx.empty()) return -4;          // host-evaluated factors need the host in the loop: use april_graph_cholesky
     pack_states(gp, g, false);
     const bool reused = prepare_plan(c, gp, g);
     upload_factors(gp);
@@ -1304,6 +1385,7 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
     Context &c = ctx_for(param);
     GraphPack &gp = pack_for(g);
     pack_factors(gp, g);
+    if (!gp.host_idx.empty()) return -4;
     pack_states(gp, g, false);
     prepare_plan(c, gp, g);
     upload_factors(gp);

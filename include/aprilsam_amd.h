@@ -63,7 +63,8 @@ typedef struct april_graph_factor april_graph_factor_t;
 typedef struct april_graph_node   april_graph_node_t;
 
 /* aprilsam.h:98-146 — 104 bytes. The device path recognises type 1 (xyt) and 2 (xytpos) and reads
- * nodes[], u.common.z and u.common.W directly; function pointers are never called on the device. */
+ * nodes[], u.common.z and u.common.W directly; function pointers are never called on the device.
+ * Any other type (1 or 2 nodes) is evaluated on the HOST through ->eval(), as aprilsam.c:156 does. */
 struct april_graph_factor {
     int   type;
     int   nnodes;
@@ -195,7 +196,13 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *   "use_graph"         1 = replay the numeric phase from a captured hipGraph (default 1)
  *   "device_timing"     1 = record per-stage HIP events (default 0)
  *   "trust_factor_cache" 1 = z/W of already-seen factors are immutable (default 1)
- *   "small_lds_kb"      fronts whose LDS image fits this many KiB use the single-workgroup kernel (100) */
+ *   "small_lds_kb"      LDS budget (KiB) of the single-workgroup front kernel: fronts whose whole array fits run fully
+ *                       in LDS, fronts whose own columns fit run in panel mode, the rest takes the multi-workgroup
+ *                       path (default 156; 0 forces the multi-workgroup path everywhere)
+ *   "panel_mode"        0 = no panel mode (fronts that do not fit LDS entirely go to the multi-workgroup path) (1)
+ *   "small_threads"     workgroup size of the single-workgroup front kernel: 256 / 512 / 1024 (default 512)
+ *   "syrk128_rows"      trailing updates at least this tall use the LDS-staged 128x128 MFMA kernel (default off)
+ *   "inc_fast"          0 = every incremental step re-plans (default 1: frozen base plan + dirty root paths) */
 int aprilsam_amd_set_option(const char *name, double value);
 
 /* ---- device-resident benchmark/driver API: states stay in HBM between iterations -------------

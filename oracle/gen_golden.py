@@ -7,6 +7,7 @@ arrays (inputs + expected outputs) so the tests can run where the reference tree
 
     python oracle/gen_golden.py            # everything except the slow 100k lattice
     python oracle/gen_golden.py --big      # also K=316 (config 4), ~2 minutes of reference CPU time
+    python oracle/gen_golden.py --custom   # ONLY the foreign-factor scenario (tests/support/custom_scenario.py)
 """
 import argparse
 import os
@@ -44,11 +45,20 @@ def batch_trace(ref, arrays, iters, keep_first=True):
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--big", action="store_true"); a = ap.parse_args()
+    ap = argparse.ArgumentParser(); ap.add_argument("--big", action="store_true"); ap.add_argument("--custom", action="store_true")
+    a = ap.parse_args()
     import ctypes as C
     os.makedirs(GOLD, exist_ok=True)
     ref = host.SolverLib(REFLIB)
     ref.dll.rs_param_U_nnz.restype = C.c_longlong
+    if a.custom:      # factor types the reference only knows through their vtable
+        import tempfile
+        from tests.support import custom_scenario
+        cl = custom_scenario.build_custom_lib(tempfile.mkdtemp())
+        out = custom_scenario.run(ref, cl)
+        np.savez_compressed(os.path.join(GOLD, "custom_factors.npz"), **out)
+        print("custom factors: chi2", out["chi2"])
+        return
     prod = host.SolverLib()          # only its data generators are used here (lattice arrays)
 
     # 1. M3500 input, parsed once from the reference's data file (data fixture)
