@@ -8,6 +8,9 @@
 // callers; the solver entry points never call them — factors of type 1/2 are evaluated by the HIP
 // kernels (csrc/kernels.hip.h).
 #include <cmath>
+#include <string>
+#include <utility>
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 
@@ -87,12 +90,41 @@ april_graph_factor_eval_t *xyt_eval_at(april_graph_factor_t *f, april_graph_t *g
 }
 april_graph_factor_eval_t *xyt_eval(april_graph_factor_t *f, april_graph_t *g, april_graph_factor_eval_t *e) { return xyt_eval_at(f, g, e, false); }
 april_graph_factor_eval_t *xyt_state_eval(april_graph_factor_t *f, april_graph_t *g, april_graph_factor_eval_t *e) { return xyt_eval_at(f, g, e, true); }
+// ---- attributes ----------------------------------------------------------------------------------------------
+// The reference hangs a zhash of typed values off node->attr / factor->attr / graph->attr (april_graph.c:101-176).  This
+// library keeps only what the `.graph` files of the path need: string values ("type" = "odom" / "scan" on the demo's
+// factors, examples/aprilsam_demo.c:84-86), in insertion order.  The block starts with a tag so that an attr pointer
+// set by the REFERENCE library (whose block starts with a heap pointer) is recognised as foreign and left alone.
+constexpr unsigned long long ATTR_TAG = 0x617474725f616d64ULL;       // "attr_amd"
+struct AmdAttr { unsigned long long tag = ATTR_TAG; std::vector<std::pair<std::string, std::string>> kv; };
+AmdAttr *own_attr(const void *p) { return (p && *(const unsigned long long *)p == ATTR_TAG) ? (AmdAttr *)p : nullptr; }
+void attr_free(void *p) { if (AmdAttr *a = own_attr(p)) delete a; }
+void *attr_clone(const void *p) { const AmdAttr *a = own_attr(p); return a ? new AmdAttr(*a) : nullptr; }
+int attr_put(void **slot, const char *key, const char *value) {
+    if (!key || !value) return -1;
+    if (*slot && !own_attr(*slot)) return -2;                        // attributes owned by another library
+    if (!*slot) *slot = new AmdAttr();
+    AmdAttr *a = (AmdAttr *)*slot;
+    for (auto &kv : a->kv) if (kv.first == key) { kv.second = value; return 0; }
+    a->kv.emplace_back(key, value);
+    return 0;
+}
+const char *attr_get(const void *p, const char *key) {
+    const AmdAttr *a = own_attr(p);
+    if (!a || !key) return nullptr;
+    for (auto &kv : a->kv) if (kv.first == key) return kv.second.c_str();
+    return nullptr;
+}
+
 void factor_destroy(april_graph_factor_t *f) {
     free(f->nodes); free(f->u.common.z); free(f->u.common.ztruth); free(f->u.common.W);
-    free(f);      // attributes (attr) are outside this path and never set by this library
+    attr_free(f->attr);
+    free(f);
 }
 april_graph_factor_t *xyt_copy(april_graph_factor_t *f) {
-    return april_graph_factor_xyt_create(f->nodes[0], f->nodes[1], f->u.common.z, f->u.common.ztruth, f->u.common.W);
+    april_graph_factor_t *c = april_graph_factor_xyt_create(f->nodes[0], f->nodes[1], f->u.common.z, f->u.common.ztruth, f->u.common.W);
+    c->attr = attr_clone(f->attr);            // the reference's copy keeps the attributes (the demo reads "type" from the copy)
+    return c;
 }
 
 // ---- xytpos factor ----------------------------------------------------------------------------------------
@@ -108,7 +140,9 @@ april_graph_factor_eval_t *xytpos_eval(april_graph_factor_t *f, april_graph_t *g
     return e;
 }
 april_graph_factor_t *xytpos_copy(april_graph_factor_t *f) {
-    return april_graph_factor_xytpos_create(f->nodes[0], f->u.common.z, f->u.common.ztruth, f->u.common.W);
+    april_graph_factor_t *c = april_graph_factor_xytpos_create(f->nodes[0], f->u.common.z, f->u.common.ztruth, f->u.common.W);
+    c->attr = attr_clone(f->attr);
+    return c;
 }
 
 // ---- xyt node ----------------------------------------------------------------------------------------------
@@ -120,11 +154,12 @@ void node_update(april_graph_node_t *n, double *d) {             // april_graph_
 }
 void node_relinearize(april_graph_node_t *n) { memcpy(n->l_point, n->state, 24); }    // april_graph_xyt.c:316-320
 void node_destroy(april_graph_node_t *n) {
-    free(n->state); free(n->init); free(n->truth); free(n->l_point); free(n->delta_X); free(n);
+    free(n->state); free(n->init); free(n->truth); free(n->l_point); free(n->delta_X); attr_free(n->attr); free(n);
 }
 april_graph_node_t *node_copy(april_graph_node_t *n) {
     april_graph_node_t *c = april_graph_node_xyt_create(n->state, n->init, n->truth);
     memcpy(c->l_point, n->l_point, 24); memcpy(c->delta_X, n->delta_X, 24);
+    c->attr = attr_clone(n->attr);
     return c;
 }
 
@@ -148,6 +183,7 @@ void april_graph_destroy(april_graph_t *g) {
     for (int i = 0; i < g->factors->size; i++) fs[i]->destroy(fs[i]);
     free(g->nodes->data); free(g->nodes);
     free(g->factors->data); free(g->factors);
+    attr_free(g->attr);
     free(g);
 }
 
@@ -203,6 +239,16 @@ int april_graph_dof(april_graph_t *g) {                                  // apri
 
 void aprilsam_amd_graph_add_node(april_graph_t *g, april_graph_node_t *n) { zarray_append(g->nodes, &n); }
 void aprilsam_amd_graph_add_factor(april_graph_t *g, april_graph_factor_t *f) { zarray_append(g->factors, &f); }
+
+int aprilsam_amd_attr_put_string(void **attr_slot, const char *key, const char *value) { return attr_slot ? attr_put(attr_slot, key, value) : -1; }
+const char *aprilsam_amd_attr_get_string(const void *attr, const char *key) { return attr_get(attr, key); }
+int aprilsam_amd_attr_count(const void *attr) { const AmdAttr *a = own_attr(attr); return a ? (int)a->kv.size() : 0; }
+int aprilsam_amd_attr_item(const void *attr, int i, const char **key, const char **value) {
+    const AmdAttr *a = own_attr(attr);
+    if (!a || i < 0 || i >= (int)a->kv.size()) return -1;
+    *key = a->kv[i].first.c_str(); *value = a->kv[i].second.c_str();
+    return 0;
+}
 
 void aprilsam_amd_graph_from_arrays(april_graph_t *g, int N, const double *states, int F, const int *fa, const int *fb,
                                     const double *z, const double *W) {

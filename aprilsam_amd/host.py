@@ -12,6 +12,7 @@ This module is plumbing only: no numerics happen in Python.
 """
 import ctypes as C
 import os
+import os
 
 import numpy as np
 
@@ -81,9 +82,18 @@ class SolverLib:
             d.aprilsam_amd_plan_query.restype = C.c_longlong
             d.aprilsam_amd_plan_query.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(C.c_longlong))]
             d.aprilsam_amd_free.argtypes = [C.c_void_p]
+            d.aprilsam_amd_graph_save_ex.argtypes = [C.POINTER(abi.Graph), C.c_char_p, C.c_ulonglong]
+            d.aprilsam_amd_graph_load.restype = C.POINTER(abi.Graph)
+            d.aprilsam_amd_graph_load.argtypes = [C.c_char_p]
+            d.aprilsam_amd_attr_put_string.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.c_char_p]
+            d.aprilsam_amd_attr_get_string.restype = C.c_char_p
+            d.aprilsam_amd_attr_get_string.argtypes = [C.c_void_p, C.c_char_p]
         else:  # the reference + oracle/ref_shim.c helpers
             self._add_node = d.rs_graph_add_node
             self._add_factor = d.rs_graph_add_factor
+        d.april_graph_save.argtypes = [C.POINTER(abi.Graph), C.c_char_p]
+        d.april_graph_create_from_file.restype = C.POINTER(abi.Graph)
+        d.april_graph_create_from_file.argtypes = [C.c_char_p]
         self._add_node.argtypes = [C.POINTER(abi.Graph), C.POINTER(abi.Node)]
         self._add_factor.argtypes = [C.POINTER(abi.Graph), C.POINTER(abi.Factor)]
         self._libc = C.CDLL(None)
@@ -114,6 +124,16 @@ class SolverLib:
 
     def new_graph(self):
         return Graph(self)
+
+    def load_graph(self, path):
+        """april_graph_create_from_file (april_graph.c:398-426); None when the file cannot be read"""
+        if not self.is_product:
+            self.dll.april_graph_stype_init(); self.dll.stype_register_basic_types()
+        p = self.dll.april_graph_create_from_file(os.fsencode(path))
+        if not p:
+            return None
+        g = Graph.__new__(Graph); g.lib = self; g.ptr = p
+        return g
 
     def new_param(self, **kw):
         return Param(self, **kw)
@@ -189,6 +209,40 @@ class Graph:
         fn = self.lib.dll.aprilsam_amd_graph_from_arrays if self.lib.is_product else self.lib.dll.rs_build_from_arrays
         fn.argtypes = [C.POINTER(abi.Graph), C.c_int, _dp, C.c_int, _ip, _ip, _dp, _dp]
         fn(self.ptr, len(states), _np_d(states), len(fa), _np_i(fa), _np_i(fb), _np_d(z), _np_d(W))
+
+    def save(self, path, magic_offset=0):
+        """april_graph_save (april_graph.c:377-396): True on success"""
+        if self.lib.is_product:
+            return self.lib.dll.aprilsam_amd_graph_save_ex(self.ptr, os.fsencode(path), int(magic_offset)) == 1
+        self.lib.dll.april_graph_stype_init(); self.lib.dll.stype_register_basic_types()
+        return self.lib.dll.april_graph_save(self.ptr, os.fsencode(path)) == 1
+
+    def factor_attr_put(self, i, key, value):
+        f = self.factor(i)
+        slot = C.cast(C.byref(f, abi.Factor.attr.offset), C.POINTER(C.c_void_p))
+        rc = self.lib.dll.aprilsam_amd_attr_put_string(slot, key.encode(), value.encode())
+        if rc != 0:
+            raise RuntimeError(f"attr_put rc={rc}")
+
+    def factor_attr_get(self, i, key):
+        v = self.lib.dll.aprilsam_amd_attr_get_string(self.factor(i).attr, key.encode())
+        return v.decode() if v is not None else None
+
+    def arrays(self):
+        """(states, fa, fb, z, W) of an xyt / xytpos graph, fb = -1 for priors"""
+        n, F = self.n_nodes, self.n_factors
+        fa = np.zeros(F, np.int32); fb = np.full(F, -1, np.int32); z = np.zeros((F, 3)); W = np.zeros((F, 9))
+        for i in range(F):
+            f = self.factor(i)
+            fa[i] = f.nodes[0]
+            if f.nnodes == 2:
+                fb[i] = f.nodes[1]
+            zz = f.u.z; Wd = f.u.W.contents.data
+            for k in range(3):
+                z[i, k] = zz[k]
+            for k in range(9):
+                W[i, k] = Wd[k]
+        return self.states(), fa, fb, z, W
 
     # -- accessors ------------------------------------------------------------------------------
     @property

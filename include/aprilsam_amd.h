@@ -158,6 +158,14 @@ april_graph_factor_t *april_graph_factor_xyt_create(int a, int b, const double *
 april_graph_factor_t *april_graph_factor_xytpos_create(int a, double *z, double *ztruth, matd_t *W);
 void april_graph_factor_eval_destroy(april_graph_factor_eval_t *eval);
 int  april_graph_dof(april_graph_t *graph);
+/* `.graph` files: replaces april_graph_save / april_graph_create_from_file
+ * (april_graph.c:377-426) and the object stream under them (common/stype.c:75-169, encode_bytes.h:120-250) for xyt
+ * nodes and xyt / xytpos factors.  save returns 1 on success, 0 on failure (the reference's convention); load
+ * returns NULL on failure.  String attributes survive a round trip (see aprilsam_amd_attr_*); attribute values of
+ * other types are skipped on input. */
+int            april_graph_save(april_graph_t *graph, const char *path);
+april_graph_t *april_graph_create_from_file(const char *path);
+void           april_graph_stype_init(void);      /* april_graph.c:367-375; nothing to register here */
 
 /* ------------------------------------------------------------------------------------------------
  * PART 4 — extensions (prefix aprilsam_amd_). Not part of the reference API.
@@ -167,6 +175,22 @@ int  april_graph_dof(april_graph_t *graph);
  * exported symbol there either; these two do the same append for callers without that header. */
 void aprilsam_amd_graph_add_node(april_graph_t *graph, april_graph_node_t *node);
 void aprilsam_amd_graph_add_factor(april_graph_t *graph, april_graph_factor_t *factor);
+
+/* String attributes (the only kind the `.graph` files of the path carry: "type" = "odom" | "scan" on the demo's
+ * factors, examples/aprilsam_demo.c:84-86; reference API: april_graph_*_attr_put/get, april_graph.c:101-176).
+ * attr_slot is &node->attr, &factor->attr or &graph->attr of an object created by THIS library; a slot already
+ * holding the reference library's attribute table is refused (-2).  Objects' copy()/destroy() carry them along. */
+int         aprilsam_amd_attr_put_string(void **attr_slot, const char *key, const char *value);
+const char *aprilsam_amd_attr_get_string(const void *attr, const char *key);
+int         aprilsam_amd_attr_count(const void *attr);
+int         aprilsam_amd_attr_item(const void *attr, int i, const char **key, const char **value);
+
+/* Same as april_graph_save / april_graph_create_from_file.  save_ex starts the per-object magic counter of the file
+ * format `magic_offset` objects later, which reproduces byte for byte what a reference process writes after it has
+ * already encoded that many objects (csrc/graph_io.cpp; data/M3500.graph: 8 * 5453). */
+int            aprilsam_amd_graph_save(april_graph_t *graph, const char *path);
+int            aprilsam_amd_graph_save_ex(april_graph_t *graph, const char *path, unsigned long long magic_offset);
+april_graph_t *aprilsam_amd_graph_load(const char *path);
 
 /* Number of usable HIP devices (0 => every solver entry point fails loudly). */
 int aprilsam_amd_device_count(void);

@@ -30,23 +30,39 @@ def test_c_driver_compiles_as_plain_c_and_parses_its_flags(built, tmp_path):
     st, fa, fb, z, W = datasets.parse_vertex_edge_text(txt)             # lossless round trip of the loader format
     a = datasets.m3500_arrays()
     assert np.array_equal(st, a[0]) and np.array_equal(z, a[3]) and np.array_equal(W, a[4]) and np.array_equal(fa, a[1])
+    # loader + writer of the C program, no solver call (--max_poses 0): text in, the reference's own data/M3500.graph out
+    import hashlib
+    from tests.test_graph_io import REF_M3500_GRAPH_SHA256
+    out = str(tmp_path / "loaded.graph")
+    r = subprocess.run([exe, "--datapath", txt, "--savepath", out, "--max_poses", "0"], capture_output=True, text=True)
+    assert r.returncode == 0 and "3500 nodes,  factors: 5453" in r.stdout, r.stderr
+    assert hashlib.sha256(open(out, "rb").read()).hexdigest() == REF_M3500_GRAPH_SHA256
+    r = subprocess.run([exe, "--graphpath", out, "--max_poses", "0"], capture_output=True, text=True)     # and back in
+    assert r.returncode == 0 and "3500 nodes,  factors: 5453" in r.stdout
+    r = subprocess.run([exe, "--graphpath", str(tmp_path / "nope.graph")], capture_output=True, text=True)
+    assert r.returncode == 2
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["inc", "batch"])
+@pytest.mark.parametrize("mode", ["inc", "batch", "inc_from_graph_file"])
 def test_c_driver_reproduces_the_reference_demo(built, tmp_path, mode):
     exe = _build(tmp_path)
     txt = str(tmp_path / "m.txt")
     datasets.write_vertex_edge_text(txt, *datasets.m3500_arrays())
-    n = 300 if mode == "inc" else 120
-    args = [exe, "--datapath", txt, "--max_poses", str(n), "--nthreshold", "100", "--delta_xy", "0.1", "--delta_theta", "0.1"]
+    n = 120 if mode == "batch" else 300
+    src = ["--datapath", txt]
+    if mode == "inc_from_graph_file":           # the reference demo's default input is the .graph file (examples/aprilsam_demo.c:249,262)
+        gpath = str(tmp_path / "m.graph")
+        assert subprocess.run([exe, "--datapath", txt, "--savepath", gpath, "--max_poses", "0"], capture_output=True).returncode == 0
+        src = ["--graphpath", gpath]
+    args = [exe] + src + ["--max_poses", str(n), "--nthreshold", "100", "--delta_xy", "0.1", "--delta_theta", "0.1"]
     if mode == "batch":
         args.append("--batch_update_only")
     r = subprocess.run(args, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     chi2 = np.array([float(x) for x in re.findall(r"Chi squared error: ([-0-9.eE+]+)", r.stdout)])
     assert len(chi2) == n
-    if mode == "inc":
+    if mode != "batch":
         G = golden("m3500_inc_demo.npz")["chi2"][:n]
         assert np.max(np.abs(chi2 - G) / np.maximum(G, 1e-6)) < 1e-5      # the driver prints %f: 6 decimals
     else:
