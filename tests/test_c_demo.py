@@ -13,10 +13,10 @@ from tests.conftest import golden
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "aprilsam_demo_amd")
+def _build(tmp_path, name="aprilsam_demo_amd"):
+    exe = str(tmp_path / name)
     libdir = os.path.join(ROOT, "aprilsam_amd", "lib")
-    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "aprilsam_demo_amd.c"),
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"),
                            "-L" + libdir, "-laprilsam_amd", "-Wl,-rpath," + libdir, "-lm", "-o", exe])
     return exe
 
@@ -67,3 +67,25 @@ def test_c_driver_reproduces_the_reference_demo(built, tmp_path, mode):
         assert np.max(np.abs(chi2 - G) / np.maximum(G, 1e-6)) < 1e-5      # the driver prints %f: 6 decimals
     else:
         assert chi2[0] == 0.0 and np.all(np.isfinite(chi2)) and chi2[-1] < 50.0
+
+
+def test_tutorial_driver_compiles_and_parses_its_flags(built, tmp_path):
+    exe = _build(tmp_path, "aprilsam_tutorial_amd")
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage:" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["inc", "batch"])
+def test_tutorial_driver_matches_reference_golden(built, tmp_path, mode):
+    """examples/aprilsam_tutorial.c:80-266 scenario; the driver prints chi^2 with %f and states with %.2f (:67-76)"""
+    exe = _build(tmp_path, "aprilsam_tutorial_amd")
+    r = subprocess.run([exe] + (["--batch_update_only"] if mode == "batch" else []), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    G = golden("tutorial_batch.npz" if mode == "batch" else "tutorial_inc.npz")
+    chi2 = np.array([float(x) for x in re.findall(r"Chi squared error: ([-0-9.eE+]+)", r.stdout)])
+    assert len(chi2) == 6 and np.max(np.abs(chi2 - G["chi2"])) < 2e-6
+    blocks = r.stdout.split("==================== Step:")[1:]
+    for k, blk in enumerate(blocks):
+        st = np.array([[float(v) for v in m] for m in re.findall(r"node_\d+ = \{([-0-9.]+), ([-0-9.]+), ([-0-9.]+)\}", blk)])
+        assert st.shape == (k + 1, 3) and np.max(np.abs(st - G[f"states_{k}"])) < 0.0051
