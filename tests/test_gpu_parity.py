@@ -79,12 +79,13 @@ def test_tutorial_batch_mode_matches_reference_golden(lib):
     assert res[-1][0] == pytest.approx(7.805041, abs=1e-6)
 
 
-@pytest.mark.parametrize("opts", [dict(small_lds_kb=0, medium_lds_kb=0), dict(small_lds_kb=0), dict(small_lds_kb=156),
-                                  dict(medium_lds_kb=0), dict(leaf_nodes=4), dict(leaf_nodes=40), dict(use_graph=0), dict(device_timing=1)])
+@pytest.mark.parametrize("opts", [dict(small_lds_kb=0), dict(small_lds_kb=48), dict(small_lds_kb=156), dict(panel_mode=0, small_lds_kb=64),
+                                  dict(small_threads=256), dict(small_threads=1024), dict(syrk128_rows=64, small_lds_kb=0),
+                                  dict(leaf_nodes=4), dict(leaf_nodes=40), dict(use_graph=0), dict(device_timing=1)])
 def test_every_kernel_path_agrees_with_oracle(lib, oracle, opts):
-    """force the multi-workgroup big-front path, the single-workgroup L2 (medium) path, the LDS path, other
-    leaf sizes, no hipGraph: same answers"""
-    defaults = dict(small_lds_kb=156, medium_lds_kb=0, leaf_nodes=16, use_graph=1, device_timing=0)
+    """force the multi-workgroup big-front path (with and without the LDS-staged MFMA tile kernel), small LDS budgets
+    (more panel-mode and big fronts), panel mode off, other workgroup sizes and leaf sizes, no hipGraph: same answers"""
+    defaults = dict(small_lds_kb=156, panel_mode=1, small_threads=512, syrk128_rows=1 << 30, leaf_nodes=16, use_graph=1, device_timing=0)
     arr = datasets.random_pose_graph(700, 600, 21)
     oc, ost = oracle.iterate(arr, 2)
     try:
@@ -98,6 +99,36 @@ def test_every_kernel_path_agrees_with_oracle(lib, oracle, opts):
     assert np.max(np.abs(snaps[-1][0] - ost)) < STATE_ATOL
     if "device_timing" in opts:
         assert stats["ms_dev_factor"] > 0
+
+
+def _star(n_leaves, seed):
+    """hub 0 connected to every other pose: one separator (the hub), n_leaves children of the root front"""
+    rng = np.random.default_rng(seed)
+    ang = rng.uniform(-np.pi, np.pi, n_leaves); rad = rng.uniform(1, 20, n_leaves)
+    st = np.vstack([[0, 0, 0], np.column_stack([rad * np.cos(ang), rad * np.sin(ang), rng.uniform(-np.pi, np.pi, n_leaves)])])
+    fa = np.zeros(n_leaves, np.int32); fb = np.arange(1, n_leaves + 1, dtype=np.int32)
+    z = np.column_stack([st[1:, 0] + rng.normal(0, .1, n_leaves), st[1:, 1] + rng.normal(0, .1, n_leaves), st[1:, 2] + rng.normal(0, .02, n_leaves)])
+    W = np.tile(np.diag([50.0, 50.0, 200.0]).reshape(9), (n_leaves, 1))
+    return datasets.with_prior(st, fa, fb, z, W, first=True)
+
+
+def _chain(n, seed):
+    rng = np.random.default_rng(seed)
+    st = np.column_stack([np.arange(n, dtype=float), rng.normal(0, .2, n), rng.normal(0, .05, n)])
+    fa = np.arange(n - 1, dtype=np.int32); fb = fa + 1
+    z = np.column_stack([np.ones(n - 1), np.zeros(n - 1), np.zeros(n - 1)])
+    W = np.tile(np.diag([100.0, 100.0, 400.0]).reshape(9), (n - 1, 1))
+    return datasets.with_prior(st, fa, fb, z, W, first=False)
+
+
+@pytest.mark.parametrize("name,arr", [("star_3000", _star(3000, 1)), ("star_70", _star(70, 2)), ("chain_4000", _chain(4000, 3))])
+def test_degenerate_tree_shapes_agree_with_oracle(lib, oracle, name, arr):
+    """a front with thousands of children (more than the staged child records and many work-list refills) and a
+    path graph (deep, thin elimination tree)"""
+    oc, ost = oracle.iterate(arr, 2)
+    chi2, snaps, _ = run_batch(lib, arr, 2)
+    assert np.max(np.abs(chi2 - oc)) < 1e-8 * oc[0]           # (every leaf of the star can satisfy its single factor: chi^2 -> 0)
+    assert np.max(np.abs(snaps[-1][0] - ost)) < STATE_ATOL
 
 
 def test_side_effects_on_the_graph_follow_the_reference(lib):

@@ -49,7 +49,7 @@ def case(name, arr, iters=1, opts=None, tol=1e-6):
         return False
     finally:
         for k in opts:
-            lib.set_option(k, {"small_lds_kb": 156, "medium_lds_kb": 0, "leaf_nodes": 16, "use_graph": 1}[k])
+            lib.set_option(k, {"small_lds_kb": 156, "leaf_nodes": 16, "use_graph": 1}[k])
 
 
 quick = "--quick" in sys.argv
@@ -59,16 +59,16 @@ tiny = (np.array([[0.1, 0.2, 0.3], [1.0, 0.1, 0.2]]), np.array([0, 0], np.int32)
 res.append(case("tiny 2 nodes (1 front)", tiny, 2, {"use_graph": 0}))
 res.append(case("random 12 (leaf 4)", datasets.random_pose_graph(12, 6, 0), 3, {"leaf_nodes": 4, "use_graph": 0}))
 res.append(case("random 80 small path", datasets.random_pose_graph(80, 60, 1), 3, {"use_graph": 0}))
-res.append(case("random 80 BIG path only", datasets.random_pose_graph(80, 60, 1), 3, {"small_lds_kb": 0, "medium_lds_kb": 0, "use_graph": 0}))
+res.append(case("random 80 BIG path only", datasets.random_pose_graph(80, 60, 1), 3, {"small_lds_kb": 0, "use_graph": 0}))
 res.append(case("random 80 MEDIUM path only", datasets.random_pose_graph(80, 60, 1), 3, {"small_lds_kb": 0, "use_graph": 0}))
 res.append(case("random 400 mixed", datasets.random_pose_graph(400, 350, 2), 3, {"use_graph": 0}))
-res.append(case("random 400 BIG path only", datasets.random_pose_graph(400, 350, 2), 3, {"small_lds_kb": 0, "medium_lds_kb": 0, "use_graph": 0}))
+res.append(case("random 400 BIG path only", datasets.random_pose_graph(400, 350, 2), 3, {"small_lds_kb": 0, "use_graph": 0}))
 res.append(case("random 400 MEDIUM path only", datasets.random_pose_graph(400, 350, 2), 3, {"small_lds_kb": 0, "use_graph": 0}))
 res.append(case("random 400 hipGraph", datasets.random_pose_graph(400, 350, 2), 3))
 res.append(case("lattice 24", lib.lattice_arrays(24), 2, {"use_graph": 0}))
 res.append(case("M3500 no graph", datasets.m3500_batch(), 3, {"use_graph": 0}))
 res.append(case("M3500 hipGraph", datasets.m3500_batch(), 5))
-res.append(case("M3500 BIG path only", datasets.m3500_batch(), 2, {"small_lds_kb": 0, "medium_lds_kb": 0}))
+res.append(case("M3500 BIG path only", datasets.m3500_batch(), 2, {"small_lds_kb": 0}))
 res.append(case("M3500 MEDIUM path only", datasets.m3500_batch(), 2, {"small_lds_kb": 0}))
 if not quick:
     res.append(case("lattice 60", lib.lattice_arrays(60), 2))
