@@ -13,6 +13,8 @@
 #include "plan.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -112,20 +114,30 @@ struct Dinic {
     }
 };
 
+// per-vertex working state of one worker
+struct Shared {
+    std::vector<int> label, dist, loc; std::vector<char> side; int next_label = 0;
+    explicit Shared(int N) : label(N, 0), dist(N, -1), loc(N, -1), side(N, 0) {}
+};
+struct Item { std::vector<int> verts; int parent; };
+
 struct Dissector {
     int N;
     const std::vector<int> &ap, &ai;
     const double *xy;
     int leaf;
-    NDTree &tree;
-    std::vector<int> label;     // region label of each vertex, -1 once placed in a tree node
-    int next_label = 0;
-    std::vector<int> dist, loc; // scratch (size N)
-    std::vector<char> side;     // scratch (size N)
+    NDTree &tree;               // the (sub)tree this worker appends to: private per worker
+    // Per-vertex scratch of this worker (every access to dist / loc / side of a neighbour is guarded by
+    // "label[neighbour] == my region"; vertices outside the worker's regions keep label 0).
+    Shared &sh;
+    int *dist, *loc; char *side;
     Dinic dinic;                // scratch of refine_band
 
-    Dissector(int N_, const std::vector<int> &ap_, const std::vector<int> &ai_, const double *xy_, int leaf_, NDTree &t)
-        : N(N_), ap(ap_), ai(ai_), xy(xy_), leaf(leaf_), tree(t), label(N_, 0), dist(N_, -1), loc(N_, -1), side(N_, 0) {}
+    Dissector(int N_, const std::vector<int> &ap_, const std::vector<int> &ai_, const double *xy_, int leaf_, NDTree &t, Shared &sh_)
+        : N(N_), ap(ap_), ai(ai_), xy(xy_), leaf(leaf_), tree(t), sh(sh_), dist(sh_.dist.data()), loc(sh_.loc.data()), side(sh_.side.data()) {}
+    int lab(int v) const { return sh.label[v]; }
+    void set_lab(int v, int L) { sh.label[v] = L; }
+    int new_label() { return ++sh.next_label; }
 
     int new_node(std::vector<int> &&verts, int parent) {
         int id = (int)tree.nodes.size();
@@ -142,7 +154,7 @@ struct Dissector {
             int u = order[h];
             for (int e = ap[u]; e < ap[u + 1]; e++) {
                 int v = ai[e];
-                if (label[v] == L && dist[v] < 0) { dist[v] = dist[u] + 1; order.push_back(v); }
+                if (lab(v) == L && dist[v] < 0) { dist[v] = dist[u] + 1; order.push_back(v); }
             }
         }
     }
@@ -154,7 +166,7 @@ struct Dissector {
         std::vector<int> B0, B1;
         for (int v : comp) {
             bool b = false;
-            for (int e = ap[v]; e < ap[v + 1] && !b; e++) { int w = ai[e]; b = (label[w] == L && side[w] != side[v]); }
+            for (int e = ap[v]; e < ap[v + 1] && !b; e++) { int w = ai[e]; b = (lab(w) == L && side[w] != side[v]); }
             if (b) { if (side[v] == 0) { loc[v] = (int)B0.size(); B0.push_back(v); } else { loc[v] = (int)B1.size(); B1.push_back(v); } }
         }
         if (B0.empty() || B1.empty()) { out.ok = false; return; }
@@ -162,7 +174,7 @@ struct Dissector {
         hk.ptr.assign(hk.nl + 1, 0);
         for (int i = 0; i < hk.nl; i++) {
             int v = B0[i];
-            for (int e = ap[v]; e < ap[v + 1]; e++) { int w = ai[e]; if (label[w] == L && side[w] == 1) hk.idx.push_back(loc[w]); }
+            for (int e = ap[v]; e < ap[v + 1]; e++) { int w = ai[e]; if (lab(w) == L && side[w] == 1) hk.idx.push_back(loc[w]); }
             hk.ptr[i + 1] = (int)hk.idx.size();
         }
         hk.run();
@@ -203,7 +215,7 @@ struct Dissector {
         for (size_t h = 0; h < band.size(); h++) {
             int u = band[h];
             if (dist[u] == width) continue;
-            for (int e = ap[u]; e < ap[u + 1]; e++) { int v = ai[e]; if (label[v] == L && dist[v] < 0) { dist[v] = dist[u] + 1; band.push_back(v); } }
+            for (int e = ap[u]; e < ap[u + 1]; e++) { int v = ai[e]; if (lab(v) == L && dist[v] < 0) { dist[v] = dist[u] + 1; band.push_back(v); } }
         }
         const int nb = (int)band.size();
         bool core0 = false, core1 = false;
@@ -216,7 +228,7 @@ struct Dissector {
             bool a0 = false, a1 = false;
             for (int e = ap[u]; e < ap[u + 1]; e++) {
                 int v = ai[e];
-                if (label[v] != L) continue;
+                if (lab(v) != L) continue;
                 if (dist[v] >= 0) fl.add(2 * i + 1, 2 * loc[v], INF);          // band -> band
                 else if (side[v] == 0) a0 = true; else a1 = true;              // neighbour in a contracted core
             }
@@ -282,23 +294,23 @@ struct Dissector {
         cut_to_separator(comp, L, out);
     }
 
-    void run() {
-        struct Item { std::vector<int> verts; int parent; };
-        std::vector<Item> stack;
-        { Item it; it.verts.resize(N); std::iota(it.verts.begin(), it.verts.end(), 0); it.parent = -1; stack.push_back(std::move(it)); }
+    // dissect the regions on `stack` to completion.  defer_below > 0: regions of at most that many vertices are not
+    // processed but moved to `deferred` (in a deterministic order) for the parallel phase.
+    void run(std::vector<Item> stack, size_t defer_below = 0, std::vector<Item> *deferred = nullptr) {
         std::vector<int> order;
         while (!stack.empty()) {
             Item item = std::move(stack.back()); stack.pop_back();
-            int L = ++next_label;
-            for (int v : item.verts) label[v] = L;
+            if (deferred && item.verts.size() <= defer_below) { deferred->push_back(std::move(item)); continue; }
+            int L = new_label();
+            for (int v : item.verts) set_lab(v, L);
             // connected components of the region
             for (int s : item.verts) {
-                if (label[s] != L) continue;
+                if (lab(s) != L) continue;
                 bfs(s, L, order);
                 std::vector<int> comp(order);
                 for (int v : comp) dist[v] = -1;
-                int Lc = ++next_label;
-                for (int v : comp) label[v] = Lc;
+                int Lc = new_label();
+                for (int v : comp) set_lab(v, Lc);
                 std::sort(comp.begin(), comp.end());
                 handle(comp, Lc, item.parent, stack);
             }
@@ -307,7 +319,7 @@ struct Dissector {
 
     template <class Stack>
     void handle(std::vector<int> &comp, int L, int parent, Stack &stack) {
-        if ((int)comp.size() <= leaf) { for (int v : comp) label[v] = -1; new_node(std::move(comp), parent); return; }
+        if ((int)comp.size() <= leaf) { for (int v : comp) set_lab(v, -1); new_node(std::move(comp), parent); return; }
         Split cand[4];
         split_geometric(comp, L, cand[0]);
         if ((int)comp.size() > 8 * leaf) {                              // the extra directions only pay near the top of the tree
@@ -328,8 +340,8 @@ struct Dissector {
             }
             if (second && second->cost < best->cost) best = second;
         }
-        if (!best) { for (int v : comp) label[v] = -1; new_node(std::move(comp), parent); return; }   // dense region
-        for (int v : best->S) label[v] = -1;
+        if (!best) { for (int v : comp) set_lab(v, -1); new_node(std::move(comp), parent); return; }   // dense region
+        for (int v : best->S) set_lab(v, -1);
         int t = new_node(std::move(best->S), parent);
         stack.push_back({ std::move(best->P0), t });
         stack.push_back({ std::move(best->P1), t });
@@ -343,8 +355,43 @@ void nested_dissection(int N, const std::vector<int> &adj_ptr, const std::vector
     tree.nodes.clear(); tree.roots.clear();
     if (N <= 0) return;
     if (leaf_nodes < 1) leaf_nodes = 1;
-    Dissector d(N, adj_ptr, adj, xy, leaf_nodes, tree);
-    d.run();
+    Shared sh(N);
+    Item all; all.verts.resize(N); std::iota(all.verts.begin(), all.verts.end(), 0); all.parent = -1;
+    std::vector<Item> top; top.push_back(std::move(all));
+    // Phase 1 (this thread): the top of the tree.  Regions of at most N/12 vertices are set aside, in a fixed order.
+    // Phase 2: every such region is dissected into a PRIVATE subtree by a pool of threads (regions are vertex-disjoint),
+    // and the subtrees are appended to the tree in that fixed order -- so the result does not depend on the number of
+    // threads or on their timing (all ranks of a sharded run and every re-run build the identical plan).
+    std::vector<Item> tasks;
+    const size_t defer_below = N >= 1024 ? (size_t)N / 12 : 0;
+    {
+        Dissector d(N, adj_ptr, adj, xy, leaf_nodes, tree, sh);
+        d.run(std::move(top), defer_below, defer_below ? &tasks : nullptr);
+    }
+    if (tasks.empty()) return;
+    const int nt = (int)tasks.size();
+    std::vector<NDTree> sub(nt);
+    auto work = [&](int i) {
+        std::vector<Item> st; Item it; it.verts = std::move(tasks[i].verts); it.parent = -1; st.push_back(std::move(it));
+        Shared mine(N);           // private per-vertex state: sharing one set of arrays between threads is correct (disjoint
+        Dissector d(N, adj_ptr, adj, xy, leaf_nodes, sub[i], mine);      // vertices) but falsely shares cache lines -- measured: no speed-up
+        d.run(std::move(st));
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    int nthreads = std::max(1, std::min({ nt, 16, hw ? (int)hw : 1 }));
+    if (const char *e = getenv("APRILSAM_AMD_PLAN_THREADS")) nthreads = std::max(1, atoi(e));      // 1 = single-threaded planning
+    if (nthreads == 1) { for (int i = 0; i < nt; i++) work(i); }
+    else {
+        std::atomic<int> next{ 0 };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; t++) pool.emplace_back([&] { for (int i; (i = next.fetch_add(1)) < nt;) work(i); });
+        for (auto &th : pool) th.join();
+    }
+    for (int i = 0; i < nt; i++) {
+        const int off = (int)tree.nodes.size(), parent = tasks[i].parent;
+        for (NDTree::Node &nd : sub[i].nodes) { for (int &c : nd.children) c += off; tree.nodes.push_back(std::move(nd)); }
+        for (int r : sub[i].roots) { if (parent < 0) tree.roots.push_back(r + off); else tree.nodes[parent].children.push_back(r + off); }
+    }
 }
 
 }  // namespace asam
