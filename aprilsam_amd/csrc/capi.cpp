@@ -102,6 +102,7 @@ void aprilsam_amd_refmodel_get(void *m, int *parent, int *changed, int *relin) {
     asam::RefModel *M = (asam::RefModel *)m;
     for (int i = 0; i < M->N; i++) { if (parent) parent[i] = M->parent[i]; if (changed) changed[i] = M->changed[i]; if (relin) relin[i] = M->relin[i]; }
 }
+int aprilsam_amd_selftest(void) { return asam::selftest(); }
 const char *aprilsam_amd_version(void) { return "aprilsam_amd 0.1 (gfx950, multifrontal FP64)"; }
 void aprilsam_amd_free(void *p) { free(p); }
 

@@ -40,6 +40,7 @@ double shard_chi2_local(april_graph_t *g, april_graph_cholesky_param_t *param);
 void shard_end(const april_graph_cholesky_param_t *param);
 int debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts);
 int api_device_count();
+int selftest();
 int api_set_device(int d);
 int api_set_option(const char *name, double v);
 

@@ -1553,6 +1553,73 @@ void shard_end(const april_graph_cholesky_param_t *param) {
     if (it != g_shard.end()) { it->second->d_flist.release(); g_shard.erase(it); }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Host-side consistency checks of the index arithmetic that host launch tables and device kernels share
+// (kernels.hip.h: syrk_range / syrk_tiles / trapezoid decode, upd_packed_offset, panel_tiles).  No GPU needed.
+// Returns 0, or a negative code naming the first failed check.
+// ------------------------------------------------------------------------------------------------------
+int selftest() {
+    // (1) outer-blocked trailing update: replay the launch sequence of one big front on the host and count, for
+    //     every element (i >= j) of the front, which panel columns k have been applied when it is consumed.
+    const int cases[][2] = { { 12, 0 }, { 12, 30 }, { 45, 17 }, { 100, 0 }, { 130, 64 }, { 43, 200 }, { 11, 11 }, { 87, 1 } };   // (nsb, nub)
+    for (auto &cs : cases) {
+        const int nsb = cs[0], nub = cs[1], nbc = nsb + nub, R = 3 * (nbc + 1), C = 3 * nbc, ns = 3 * nsb, Rv = R - 2;
+        std::vector<int> applied((size_t)Rv * C, 0);          // number of K columns applied to (i, j), j < C, i < Rv
+        std::vector<long long> ksum((size_t)Rv * C, 0);       // sum of applied k (detects duplicates / wrong columns)
+        const int steps = (ns + NB - 1) / NB;
+        auto run = [&](int s_lo, int s_hi, int mode, int tile) -> int {
+            const SyrkRange g = syrk_range(R, C, ns, s_lo, s_hi, mode, tile);
+            const int nt = syrk_tiles(R, C, ns, s_lo, s_hi, mode, tile);
+            if (nt != g.ntc * g.ntr - g.ntc * (g.ntc - 1) / 2) return -11;
+            std::vector<char> seen((size_t)std::max(1, g.ntr) * std::max(1, g.ntc), 0);
+            for (int l = 0; l < nt; l++) {
+                // same decode as trapezoid_tile (host copy of the arithmetic)
+                int tj = 0; while (tj + 1 < g.ntc && (tj + 1) * g.ntr - (tj + 1) * tj / 2 <= l) tj++;
+                const int ti = tj + (l - (tj * g.ntr - tj * (tj - 1) / 2));
+                if (ti < tj || ti >= g.ntr || seen[(size_t)tj * g.ntr + ti]++) return -12;
+                for (int j = g.col_lo + tj * tile; j < std::min(g.col_hi, g.col_lo + (tj + 1) * tile); j++)
+                    for (int i = std::max(j, g.col_lo + ti * tile); i < std::min(Rv, g.col_lo + (ti + 1) * tile); i++)
+                        for (int k = g.k_lo; k < g.k_hi; k++) { applied[(size_t)j * Rv + i]++; ksum[(size_t)j * Rv + i] += k; }
+            }
+            return 0;
+        };
+        for (int tile : { TILE, TILE2 }) {
+            std::fill(applied.begin(), applied.end(), 0); std::fill(ksum.begin(), ksum.end(), 0);
+            for (int s = 0; s < steps; s++) {
+                // when panel s is factored, each of its columns j must carry exactly the columns k < s*NB
+                const int k0 = s * NB, k1 = std::min(ns, k0 + NB);
+                for (int j = k0; j < k1; j++)
+                    for (int i = j; i < Rv; i++)
+                        if (applied[(size_t)j * Rv + i] != k0 || ksum[(size_t)j * Rv + i] != (long long)k0 * (k0 - 1) / 2) return -13;
+                int rc = run(s, s + 1, 0, TILE); if (rc) return rc;                        // narrow update (always the 64 x 64 kernel)
+                if ((s + 1) % OBP == 0 || s + 1 == steps) { rc = run(s / OBP * OBP, s + 1, 1, tile); if (rc) return rc; }
+            }
+            for (int j = ns; j < C; j++)
+                for (int i = j; i < Rv; i++)
+                    if (applied[(size_t)j * Rv + i] != ns || ksum[(size_t)j * Rv + i] != (long long)ns * (ns - 1) / 2) return -14;
+        }
+        // (2) packed Schur update: offsets are the running count of (rows from the top of the diagonal block to the rhs row)
+        long long run_off = 0;
+        for (int j = ns; j < C; j++) { if (upd_packed_offset(R, ns, j) != run_off) return -21; run_off += Rv - 3 * (j / 3); }
+        if (upd_packed_offset(R, ns, C) != run_off) return -22;
+        // (3) row tiles of the panel kernel cover the rows below every panel exactly once
+        for (int s = 0; s < steps; s++) {
+            const int k0 = s * NB, wdt = std::min(NB, ns - k0), below = Rv - (k0 + wdt);
+            const int nt = panel_tiles(R, ns, s);
+            if (nt < 1 || (long long)nt * PANEL_ROWS < below || (nt > 1 && (long long)(nt - 1) * PANEL_ROWS >= below)) return -31;
+        }
+    }
+    // (4) LDS budgets: a front classified "full" also fits as "panel", and the work-list region is what the kernel carves
+    for (int nw : { 4, 8, 16 })
+        for (int R = 6; R < 400; R += 7)
+            for (int nsb = 1; 3 * nsb < R - 3; nsb += 5) {
+                const int C = R - 3;
+                if (panel_front_lds(R, 3 * nsb, nw) > small_front_lds(R, C, nw)) return -41;
+                if (small_front_lds(R, C, nw) != (size_t)(R | 1) * C * 8 + (size_t)wl_bytes(nw)) return -42;
+            }
+    return 0;
+}
+
 int api_device_count() { return device_count(); }
 int api_set_device(int d) {
     int n = device_count();

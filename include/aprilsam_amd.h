@@ -192,6 +192,10 @@ int            aprilsam_amd_graph_save(april_graph_t *graph, const char *path);
 int            aprilsam_amd_graph_save_ex(april_graph_t *graph, const char *path, unsigned long long magic_offset);
 april_graph_t *aprilsam_amd_graph_load(const char *path);
 
+/* Host-only consistency checks of the index arithmetic shared by launch tables and kernels (tile decode of the
+ * outer-blocked trailing update, packed Schur offsets, panel row tiles, LDS budgets).  0 = all good.  No GPU needed. */
+int aprilsam_amd_selftest(void);
+
 /* Number of usable HIP devices (0 => every solver entry point fails loudly). */
 int aprilsam_amd_device_count(void);
 /* Select the HIP device used by contexts created afterwards (default: LOCAL_RANK env or 0). */

@@ -108,3 +108,9 @@ def test_solver_entry_points_fail_loudly_without_gpu(lib):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "RETURNED" not in r.stdout
     assert "no HIP device" in r.stderr
+
+
+def test_shared_index_arithmetic_selftest(lib):
+    """host replay of the outer-blocked trailing update (every element receives exactly the right panel columns before
+    it is consumed, for both MFMA tile sizes), packed Schur offsets, panel row tiles, LDS budgets — no GPU involved"""
+    assert lib.dll.aprilsam_amd_selftest() == 0
