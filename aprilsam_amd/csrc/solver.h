@@ -14,6 +14,8 @@ struct Options {
     int inc_fast = 1;             // incremental steps regenerate only the dirty root paths (0: full re-plan per step)
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
     int small_threads = 512;      // workgroup size of k_front_small (256 / 512 / 1024)
+    int tp_fronts = 1000;         // levels with at least this many fronts are "throughput levels" ...
+    int tp_lds_kb = 64;           // ... where only fronts up to this LDS size run fully in LDS (the rest: panel mode, more workgroups per CU)
     int panel_mode = 1;           // fronts too large for LDS whose own columns fit run in k_front_small's panel mode
 };
 extern Options g_opt;

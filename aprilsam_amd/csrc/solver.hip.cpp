@@ -63,6 +63,8 @@ static void load_env_options() {
         v = g_opt.syrk128_rows; envd("APRILSAM_AMD_SYRK128_ROWS", &v); g_opt.syrk128_rows = (int)v;
         v = g_opt.panel_mode; envd("APRILSAM_AMD_PANEL_MODE", &v); g_opt.panel_mode = (int)v;
         v = g_opt.small_threads; envd("APRILSAM_AMD_SMALL_THREADS", &v); g_opt.small_threads = (int)v;
+        v = g_opt.tp_fronts; envd("APRILSAM_AMD_TP_FRONTS", &v); g_opt.tp_fronts = (int)v;
+        v = g_opt.tp_lds_kb; envd("APRILSAM_AMD_TP_LDS_KB", &v); g_opt.tp_lds_kb = (int)v;
         v = g_opt.inc_fast; envd("APRILSAM_AMD_INC_FAST", &v); g_opt.inc_fast = (int)v;
     });
 }
@@ -285,6 +287,7 @@ struct Launch { int list_off, pre_off, n, grid; bool single = false; int tile = 
 
 struct LevelPlan {
     int small_off = 0, n_small = 0; size_t small_lds = 0;      // fronts handled by k_front_small
+    long long full_limit = 0;                                  // ... fully in LDS when their array fits this many bytes, else panel mode
     int n_big = 0; size_t asm_lds = 0;
     Launch asm_big{};                                          // k_assemble_big
     std::vector<Launch> panel, syrk, syrkw;                    // per panel step: diag+panel, narrow update, wide update (grid 0 unless the step closes an outer block)
@@ -400,12 +403,18 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     auto rows = [&](int t) { int a, b; dims(t, &a, &b); return 3 * (a + b + 1); };
     auto cols = [&](int t) { int a, b; dims(t, &a, &b); return 3 * (a + b); };
     auto nsb_of = [&](int t) { int a, b; dims(t, &a, &b); return a; };
+    // throughput levels (far more fronts than compute units): a lower full-LDS limit sends mid-size fronts to panel mode,
+    // whose LDS footprint (own columns only) lets several workgroups share a CU
+    size_t full_max = small_max;
+    if ((int)fronts.size() >= g_opt.tp_fronts && g_opt.tp_lds_kb > 0) full_max = std::min(small_max, (size_t)g_opt.tp_lds_kb * 1024);
+    L.full_limit = (long long)full_max;
     for (int t : fronts) {
         const int R = rows(t), C = cols(t);
         maxm = std::max<size_t>(maxm, C);
         const size_t lds_s = small_front_lds(R, C, small_waves()), lds_p = panel_front_lds(R, 3 * nsb_of(t), small_waves());
-        if (lds_s <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); }
+        if (lds_s <= full_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); }
         else if (g_opt.panel_mode && lds_p <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_p); }   // k_front_small, panel mode
+        else if (lds_s <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); L.full_limit = std::max(L.full_limit, (long long)lds_s); }
         else big.push_back(t);
     }
     // longest-processing-time first: the widest fronts of a level start first
@@ -489,7 +498,6 @@ static void upload_plan(Context &c, hipStream_t s) {
     DevPlan &d = c.dp;
     d.nF = P.nF;
     d.fd = c.d_fd.p; d.dest = c.d_dest.p; d.child = c.d_child.p;
-    d.small_lds_limit = (long long)g_opt.small_lds_kb * 1024;
     d.f_rows = c.d_i32.p; d.f_rel = c.d_i32.p; d.slot_blk = c.d_i32.p + o_sb; d.slot_rhs = c.d_i32.p + o_sr; d.src_idx = c.d_i32.p;
     c.inc.o_rows = (long long)o_rows; c.inc.o_rel = (long long)o_rel;
     d.lambda = c.d_lambda.p;
@@ -539,9 +547,9 @@ static void set_small_attr() {
 // k_front_small with the configured workgroup size (option small_threads: 256 / 512 / 1024)
 static void launch_front_small(Context &c, const LevelPlan &L, hipStream_t s) {
     const int nt = g_opt.small_threads;
-    if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
-    else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
-    else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p);
+    if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit);
+    else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit);
+    else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit);
 }
 
 // panel steps of the big fronts of one level: per NB-column panel {diagonal block, row solves, narrow update};
@@ -1640,6 +1648,8 @@ int api_set_option(const char *name, double v) {
     else if (k == "syrk128_rows") g_opt.syrk128_rows = (int)v;
     else if (k == "panel_mode") g_opt.panel_mode = (int)v;
     else if (k == "small_threads") g_opt.small_threads = (int)v;
+    else if (k == "tp_fronts") g_opt.tp_fronts = (int)v;
+    else if (k == "tp_lds_kb") g_opt.tp_lds_kb = (int)v;
     else if (k == "inc_fast") g_opt.inc_fast = (int)v;
     else return -1;
     return 0;

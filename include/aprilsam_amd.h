@@ -228,6 +228,9 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *                       in LDS, fronts whose own columns fit run in panel mode, the rest takes the multi-workgroup
  *                       path (default 156; 0 forces the multi-workgroup path everywhere)
  *   "panel_mode"        0 = no panel mode (fronts that do not fit LDS entirely go to the multi-workgroup path) (1)
+ *   "tp_fronts", "tp_lds_kb"  levels with at least tp_fronts fronts (default 1000) are throughput-bound: there only
+ *                       fronts up to tp_lds_kb KiB (default 64) run fully in LDS, larger ones use panel mode so that
+ *                       several workgroups share a compute unit
  *   "small_threads"     workgroup size of the single-workgroup front kernel: 256 / 512 / 1024 (default 512)
  *   "syrk128_rows"      trailing updates at least this tall use the LDS-staged 128x128 MFMA kernel (default off)
  *   "inc_fast"          0 = every incremental step re-plans (default 1: frozen base plan + dirty root paths) */
