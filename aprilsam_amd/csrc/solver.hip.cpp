@@ -292,6 +292,7 @@ struct LevelPlan {
     Launch asm_big{};                                          // k_assemble_big
     std::vector<Launch> panel, syrk, syrkw;                    // per panel step: diag+panel, narrow update, wide update (grid 0 unless the step closes an outer block)
     int all_off = 0, n_all = 0; size_t solve_lds = 0;          // every front (k_backsolve)
+    Launch bs_gemv{};                                          // fronts whose update-row product is spread over workgroups first (k_backsolve_gemv)
 };
 
 // state of the incremental fast path (inc_fast.*): the plan of the last batch step stays frozen, poses added since
@@ -421,6 +422,16 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     std::sort(small.begin(), small.end(), [&](int a, int b) { int ra = rows(a), rb = rows(b); return ra != rb ? ra > rb : a < b; });
     L.all_off = (int)tab.size(); L.n_all = (int)fronts.size();
     tab.insert(tab.end(), fronts.begin(), fronts.end());
+    {   // back substitution: fronts with a large update block get their update-row product from k_backsolve_gemv
+        std::vector<int> sp;
+        for (int t : fronts) { int a, b; dims(t, &a, &b); if (bs_split_front(a, b)) sp.push_back(t); }
+        L.bs_gemv = Launch{ (int)tab.size(), 0, (int)sp.size(), 0, false };
+        tab.insert(tab.end(), sp.begin(), sp.end());
+        L.bs_gemv.pre_off = (int)tab.size();
+        int acc = 0; tab.push_back(0);
+        for (int t : sp) { acc += (3 * nsb_of(t) + NB - 1) / NB; tab.push_back(acc); }
+        L.bs_gemv.grid = acc;
+    }
     L.solve_lds = (maxm + NB + 8 + NB * (NB + 1)) * 8;
     L.small_off = (int)tab.size(); L.n_small = (int)small.size();
     tab.insert(tab.end(), small.begin(), small.end());
@@ -544,6 +555,18 @@ static void set_small_attr() {
 }
 
 // kernels of one level of the factorisation (small LDS fronts, big multi-workgroup path)
+// back substitution of one level: update-row products of the large fronts on many workgroups, then one workgroup per front
+template <class Tic, class Toc>
+static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc) {
+    if (!L.n_all) return;
+    tic(K_BACKSOLVE);
+    if (L.bs_gemv.grid > 0)
+        hipLaunchKernelGGL(k_backsolve_gemv, dim3(L.bs_gemv.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + L.bs_gemv.list_off, c.d_tab.p + L.bs_gemv.pre_off,
+                           L.bs_gemv.n, c.d_pool.p, c.d_x.p);
+    hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0);
+    toc();
+}
+
 // k_front_small with the configured workgroup size (option small_threads: 256 / 512 / 1024)
 static void launch_front_small(Context &c, const LevelPlan &L, hipStream_t s) {
     const int nt = g_opt.small_threads;
@@ -634,10 +657,7 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     for (int l = 0; l < P.nLevels; l++) enqueue_factor_level(c, c.levels[l], s, tic, toc);
     if (ev) HIPCHECK(hipEventRecord(ev[2], s));
     for (int l = P.nLevels - 1; l >= 0; l--) {
-        const LevelPlan &L = c.levels[l];
-        tic(K_BACKSOLVE);
-        hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
-        toc();
+        launch_backsolve(c, c.levels[l], s, tic, toc);
     }
     HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));     // NaN sentinel = "node skipped"
     tic(K_UPDATE);
@@ -904,6 +924,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
+        L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh;
         if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
     }
     // ---- 4. uploads ------------------------------------------------------------------------------------------------
@@ -945,17 +966,17 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     }
     {   // TAIL is the root of the back substitution; its launch list is the single dirty entry of the top level
         const LevelPlan &L = dl[I.nLev0];
-        hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
+        hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0);
     }
     if (!needed) {                                   // every pose is visited: all fronts, level by level
         for (int l = I.nLev0 - 1; l >= 0; l--) {
             const LevelPlan &L = I.base_levels[l];
-            hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
+            hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0);
         }
     } else {                                         // only the fronts holding a visited pose, and their ancestors
         for (int l = I.nLev0 - 1; l >= 0; l--)
             if (bs_n[l] > 0)
-                hipLaunchKernelGGL(k_backsolve, dim3((unsigned)bs_n[l]), dim3(TPB), I.base_levels[l].solve_lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p);
+                hipLaunchKernelGGL(k_backsolve, dim3((unsigned)bs_n[l]), dim3(TPB), I.base_levels[l].solve_lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0);
     }
     HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
@@ -1177,7 +1198,7 @@ void inc_solve_only(april_graph_t *g, april_graph_cholesky_param_t *param) {
     set_small_attr();
     for (int l = P.nLevels - 1; l >= 0; l--) {
         const LevelPlan &L = c.levels[l];
-        hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
+        hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0);
     }
     HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
@@ -1444,6 +1465,7 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
         for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
+        L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh;
     }
     if (c.inc.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return -3;
     if (!tab.empty()) HIPCHECK(hipMemcpyAsync(c.d_tab.p + c.inc.tab_used, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, gp.stream));
@@ -1504,7 +1526,7 @@ int shard_step(april_graph_t *g, april_graph_cholesky_param_t *param, int op, in
         enqueue_factor_level(c, S.levels[arg], s, nop, nop0);
     } else if (op == 2) {
         const LevelPlan &L = S.levels[arg];
-        if (L.n_all) hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p);
+        launch_backsolve(c, L, s, nop, nop0);
     } else if (op == 3) {
         HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));
         hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
