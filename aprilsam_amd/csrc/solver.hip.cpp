@@ -721,8 +721,11 @@ static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g) {
     c.patN = N;
     std::vector<double> xy((size_t)2 * N);
     for (int i = 0; i < N; i++) { xy[2 * i] = gp.h_state.p[3 * i]; xy[2 * i + 1] = gp.h_state.p[3 * i + 1]; }
+    const double tb0 = now_ms();
     build_plan(c.plan, N, F, c.pat.data(), xy.data(), g_opt.leaf_nodes);
+    const double tb1 = now_ms();
     upload_plan(c, gp.stream);
+    if (getenv("APRILSAM_AMD_PLAN_PROFILE")) fprintf(stderr, "aprilsam_amd plan: N=%d build %.3f ms upload %.3f ms\n", N, tb1 - tb0, now_ms() - tb1);
     c.have_plan = true;
     return false;
 }
