@@ -65,6 +65,7 @@ static void load_env_options() {
         v = g_opt.small_threads; envd("APRILSAM_AMD_SMALL_THREADS", &v); g_opt.small_threads = (int)v;
         v = g_opt.tp_fronts; envd("APRILSAM_AMD_TP_FRONTS", &v); g_opt.tp_fronts = (int)v;
         v = g_opt.tp_lds_kb; envd("APRILSAM_AMD_TP_LDS_KB", &v); g_opt.tp_lds_kb = (int)v;
+        v = g_opt.lookahead; envd("APRILSAM_AMD_LOOKAHEAD", &v); g_opt.lookahead = (int)v;
         v = g_opt.inc_fast; envd("APRILSAM_AMD_INC_FAST", &v); g_opt.inc_fast = (int)v;
     });
 }
@@ -290,6 +291,7 @@ struct LevelPlan {
     long long full_limit = 0;                                  // ... fully in LDS when their array fits this many bytes, else panel mode
     int n_big = 0; size_t asm_lds = 0;
     Launch asm_big{};                                          // k_assemble_big
+    std::vector<Launch> syrka, syrkb;                          // look-ahead split of the wide update (modes 2, 3), same indexing as syrkw
     std::vector<Launch> panel, syrk, syrkw;                    // per panel step: diag+panel, narrow update, wide update (grid 0 unless the step closes an outer block)
     int all_off = 0, n_all = 0; size_t solve_lds = 0;          // every front (k_backsolve)
     Launch bs_gemv{};                                          // fronts whose update-row product is spread over workgroups first (k_backsolve_gemv)
@@ -353,6 +355,12 @@ struct Context {
     std::vector<int> inc_slot_blk, inc_slot_rhs;   // slots of the factors added since the base plan (3 / 2 per factor)
     RefModel model;                       // the reference's tree / counters (refmodel.cpp), rebuilt lazily after a batch
     int batch_factors = 0;                // #factors at the last batch step
+    // look-ahead: the "rest" part of the wide trailing updates runs on a side stream (enqueue_big_steps)
+    hipStream_t s2 = nullptr; std::vector<hipEvent_t> la_ev; size_t la_next = 0;
+    hipEvent_t la_event() {
+        if (la_next == la_ev.size()) { hipEvent_t e; HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); la_ev.push_back(e); }
+        return la_ev[la_next++];
+    }
     // captured numeric phase
     hipGraphExec_t gexec = nullptr;
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
@@ -365,6 +373,10 @@ struct Context {
         have_events = false;
         for (auto &e : k_ev) (void)hipEventDestroy(e);
         k_ev.clear();
+        for (auto &e : la_ev) (void)hipEventDestroy(e);
+        la_ev.clear(); la_next = 0;
+        if (s2) (void)hipStreamDestroy(s2);
+        s2 = nullptr;
     }
 };
 static std::unordered_map<const void *, std::unique_ptr<Context>> g_ctx;
@@ -462,8 +474,12 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
             const int tile = span >= g_opt.syrk128_rows ? TILE2 : TILE;
             L.syrkw.push_back(make(active(s_lo), [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, sidx + 1, 1, tile); }));
             L.syrkw.back().tile = tile;
+            L.syrka.push_back(make(active(s_lo), [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, sidx + 1, 2); }));
+            L.syrkb.push_back(make(active(s_lo), [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, sidx + 1, 3, tile); }));
+            L.syrkb.back().tile = tile;
         } else {
             L.syrkw.push_back(Launch{ 0, 0, 0, 0, false });
+            L.syrka.push_back(Launch{ 0, 0, 0, 0, false }); L.syrkb.push_back(Launch{ 0, 0, 0, 0, false });
         }
     }
 }
@@ -554,7 +570,6 @@ static void set_small_attr() {
     });
 }
 
-// kernels of one level of the factorisation (small LDS fronts, big multi-workgroup path)
 // back substitution of one level: update-row products of the large fronts on many workgroups, then one workgroup per front
 template <class Tic, class Toc>
 static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc) {
@@ -578,7 +593,19 @@ static void launch_front_small(Context &c, const LevelPlan &L, hipStream_t s) {
 // panel steps of the big fronts of one level: per NB-column panel {diagonal block, row solves, narrow update};
 // after every OBP panels one wide update with K = OBP * NB (kernels.hip.h: syrk_range)
 template <class Tic, class Toc>
-static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc) {
+static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, bool la = false) {
+    auto wide = [&](const Launch &w, int k, int mode, hipStream_t st) {
+        if (w.tile == TILE2)
+            hipLaunchKernelGGL(k_syrk_big128, dim3(w.grid), dim3(TPB), 0, st, c.dp, c.d_tab.p + w.list_off, c.d_tab.p + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
+        else
+            hipLaunchKernelGGL(k_syrk_big, dim3(w.grid), dim3(TPB), 0, st, c.dp, c.d_tab.p + w.list_off, c.d_tab.p + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
+    };
+    if (la && !c.s2) {        // lowest priority: its big kernels must not delay the one-workgroup kernels of the chain
+        int lo = 0, hi = 0;
+        HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHECK(hipStreamCreateWithPriority(&c.s2, hipStreamNonBlocking, lo));
+    }
+    hipEvent_t rest_done = nullptr;          // completion of the latest "rest" update on the side stream
     for (size_t k = 0; k < L.panel.size(); k++) {
         const Launch &pa = L.panel[k], &sy = L.syrk[k], &sw = L.syrkw[k];
         if (pa.single) {          // one row tile per front: diagonal block + row solves in one launch
@@ -598,19 +625,33 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
             hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off, sy.n, (int)k, (int)k + 1, 0, c.d_pool.p);
             toc();
         }
-        if (sw.grid > 0) {
-            tic(K_SYRK_BIG);
-            if (sw.tile == TILE2)
-                hipLaunchKernelGGL(k_syrk_big128, dim3(sw.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sw.list_off, c.d_tab.p + sw.pre_off, sw.n, (int)k / OBP * OBP, (int)k + 1, 1, c.d_pool.p);
-            else
-                hipLaunchKernelGGL(k_syrk_big, dim3(sw.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sw.list_off, c.d_tab.p + sw.pre_off, sw.n, (int)k / OBP * OBP, (int)k + 1, 1, c.d_pool.p);
-            toc();
+        if (!la) {
+            if (sw.grid > 0) { tic(K_SYRK_BIG); wide(sw, (int)k, 1, s); toc(); }
+            continue;
         }
+        // Look-ahead.  "ahead" = the next outer block's panel columns: stays on this stream, the chain of small kernels
+        // that follows needs it.  "rest" = everything right of them: side stream, overlapped with that chain.  Both read
+        // this outer block's columns and write disjoint column ranges.  The previous "rest" wrote the columns "ahead"
+        // updates now (and the ones this "rest" updates: same stream, in order), so "ahead" waits for it.
+        const Launch &sa = L.syrka[k], &sb = L.syrkb[k];
+        if (sb.grid > 0) {
+            hipEvent_t chain_done = c.la_event();
+            HIPCHECK(hipEventRecord(chain_done, s));
+            HIPCHECK(hipStreamWaitEvent(c.s2, chain_done, 0));
+            wide(sb, (int)k, 3, c.s2);
+        }
+        if (sa.grid > 0) {
+            if (rest_done) HIPCHECK(hipStreamWaitEvent(s, rest_done, 0));
+            wide(sa, (int)k, 2, s);
+        }
+        if (sb.grid > 0) { rest_done = c.la_event(); HIPCHECK(hipEventRecord(rest_done, c.s2)); }
     }
+    if (rest_done) HIPCHECK(hipStreamWaitEvent(s, rest_done, 0));      // join: the next level reads the update blocks
 }
 
+// kernels of one level of the factorisation (small LDS fronts, big multi-workgroup path)
 template <class Tic, class Toc>
-static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc) {
+static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, bool la = false) {
     if (L.n_small) {
         tic(K_FRONT_SMALL);
         launch_front_small(c, L, s);
@@ -621,7 +662,7 @@ static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, 
         hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
                            c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
         toc();
-        enqueue_big_steps(c, L, s, tic, toc);
+        enqueue_big_steps(c, L, s, tic, toc, la);
     }
 }
 
@@ -654,7 +695,8 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     }
     toc();
     if (ev) HIPCHECK(hipEventRecord(ev[1], s));
-    for (int l = 0; l < P.nLevels; l++) enqueue_factor_level(c, c.levels[l], s, tic, toc);
+    c.la_next = 0;
+    for (int l = 0; l < P.nLevels; l++) enqueue_factor_level(c, c.levels[l], s, tic, toc, !ktime && g_opt.lookahead);
     if (ev) HIPCHECK(hipEventRecord(ev[2], s));
     for (int l = P.nLevels - 1; l >= 0; l--) {
         launch_backsolve(c, c.levels[l], s, tic, toc);
@@ -927,6 +969,8 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.syrka) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.syrkb) { x.list_off += sh; x.pre_off += sh; }
         L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh;
         if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
     }
@@ -1468,6 +1512,8 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
         for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.syrka) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.syrkb) { x.list_off += sh; x.pre_off += sh; }
         L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh;
     }
     if (c.inc.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return -3;
@@ -1526,7 +1572,8 @@ int shard_step(april_graph_t *g, april_graph_cholesky_param_t *param, int op, in
             hipLaunchKernelGGL(k_linearize, dim3((S.n_flist + TPB - 1) / TPB), dim3(TPB), 0, s, 0, S.n_flist, (const int *)S.d_flist.p, gp.d_fa.p, gp.d_fb.p,
                                gp.d_z.p, gp.d_W.p, gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
     } else if (op == 1) {
-        enqueue_factor_level(c, S.levels[arg], s, nop, nop0);
+        c.la_next = 0;
+        enqueue_factor_level(c, S.levels[arg], s, nop, nop0, g_opt.lookahead != 0);
     } else if (op == 2) {
         const LevelPlan &L = S.levels[arg];
         launch_backsolve(c, L, s, nop, nop0);
@@ -1616,7 +1663,8 @@ int selftest() {
             }
             return 0;
         };
-        for (int tile : { TILE, TILE2 }) {
+        for (int variant = 0; variant < 4; variant++) {          // wide update whole / split for look-ahead, both tile sizes
+            const int tile = (variant & 1) ? TILE2 : TILE; const bool split = variant >= 2;
             std::fill(applied.begin(), applied.end(), 0); std::fill(ksum.begin(), ksum.end(), 0);
             for (int s = 0; s < steps; s++) {
                 // when panel s is factored, each of its columns j must carry exactly the columns k < s*NB
@@ -1625,7 +1673,10 @@ int selftest() {
                     for (int i = j; i < Rv; i++)
                         if (applied[(size_t)j * Rv + i] != k0 || ksum[(size_t)j * Rv + i] != (long long)k0 * (k0 - 1) / 2) return -13;
                 int rc = run(s, s + 1, 0, TILE); if (rc) return rc;                        // narrow update (always the 64 x 64 kernel)
-                if ((s + 1) % OBP == 0 || s + 1 == steps) { rc = run(s / OBP * OBP, s + 1, 1, tile); if (rc) return rc; }
+                if ((s + 1) % OBP == 0 || s + 1 == steps) {
+                    if (split) { rc = run(s / OBP * OBP, s + 1, 2, TILE); if (rc) return rc; rc = run(s / OBP * OBP, s + 1, 3, tile); if (rc) return rc; }
+                    else { rc = run(s / OBP * OBP, s + 1, 1, tile); if (rc) return rc; }
+                }
             }
             for (int j = ns; j < C; j++)
                 for (int i = j; i < Rv; i++)
@@ -1675,6 +1726,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "small_threads") g_opt.small_threads = (int)v;
     else if (k == "tp_fronts") g_opt.tp_fronts = (int)v;
     else if (k == "tp_lds_kb") g_opt.tp_lds_kb = (int)v;
+    else if (k == "lookahead") g_opt.lookahead = (int)v;
     else if (k == "inc_fast") g_opt.inc_fast = (int)v;
     else return -1;
     return 0;
