@@ -16,7 +16,7 @@ struct Options {
     int small_threads = 512;      // workgroup size of k_front_small (256 / 512 / 1024)
     int tp_fronts = 1000;         // levels with at least this many fronts are "throughput levels" ...
     int tp_lds_kb = 64;           // ... where only fronts up to this LDS size run fully in LDS (the rest: panel mode, more workgroups per CU)
-XX
+    int lookahead = 0;            // 1: wide trailing updates split, next outer block columns first, the rest on a side stream (measured: no gain)
     int panel_mode = 1;           // fronts too large for LDS whose own columns fit run in k_front_small's panel mode
 };
 extern Options g_opt;
