@@ -682,11 +682,10 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     };
     auto toc = [&]() { if (ktime) { HIPCHECK(hipEventRecord(c.k_ev[nev + 1], s)); nev += 2; } };
     if (ev) HIPCHECK(hipEventRecord(ev[0], s));
-    HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 16, s));
     if (c.dp.prof) HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)64 * P.nF, s));
     tic(K_LINEARIZE);
     hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                       gp.d_lp.p, unary_at_lp ? gp.d_lp.p : gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
+                       gp.d_lp.p, unary_at_lp ? gp.d_lp.p : gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p);
     if (!gp.host_idx.empty()) {         // host-evaluated factors: their blocks replace the null contributions written above
         const int nh = (int)gp.host_idx.size();
         HIPCHECK(hipMemcpyAsync(gp.d_hostH.p, gp.h_hostH.p, (size_t)33 * 8 * nh, hipMemcpyHostToDevice, s));
@@ -701,7 +700,6 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     for (int l = P.nLevels - 1; l >= 0; l--) {
         launch_backsolve(c, c.levels[l], s, tic, toc);
     }
-    HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));     // NaN sentinel = "node skipped"
     tic(K_UPDATE);
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
     toc();
@@ -1025,7 +1023,6 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             if (bs_n[l] > 0)
                 hipLaunchKernelGGL(k_backsolve, dim3((unsigned)bs_n[l]), dim3(TPB), I.base_levels[l].solve_lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0);
     }
-    HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
     HIPCHECK(hipGetLastError());
     for (int t : fd_dirty) I.dirty[t] = 0;
@@ -1247,7 +1244,6 @@ void inc_solve_only(april_graph_t *g, april_graph_cholesky_param_t *param) {
         const LevelPlan &L = c.levels[l];
         hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0);
     }
-    HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
     HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
@@ -1578,7 +1574,6 @@ int shard_step(april_graph_t *g, april_graph_cholesky_param_t *param, int op, in
         const LevelPlan &L = S.levels[arg];
         launch_backsolve(c, L, s, nop, nop0);
     } else if (op == 3) {
-        HIPCHECK(hipMemsetAsync(gp.d_dx.p, 0xFF, (size_t)24 * N, s));
         hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
     } else if (op == 4) {
         HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, s));
