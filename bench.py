@@ -47,6 +47,24 @@ def kernel_profile(lib, p):
     return [dict(name=names[k].decode(), ms=ms[k], calls=calls[k], flops=fl[k], bytes=by[k]) for k in range(n)]
 
 
+def big_front_roofline(prof, iters):
+    """roofline entry of the wide-supernode path (k_syrk_big: v_mfma_f64_16x16x4_f64) from an instrumented pass of `iters` iterations"""
+    k = next((q for q in prof if q["name"] == "k_syrk_big"), None)
+    if not k or k["ms"] <= 0 or k["flops"] <= 0:
+        return None
+    ach = k["flops"] / (k["ms"] / iters * 1e-3) / 1e12
+    mfma = None
+    try:
+        m = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")))["kernels"]["k_syrk_big"]
+        mfma = m["mfma_busy_over_cu_busy"]
+    except Exception:
+        pass
+    return dict(kernel="k_syrk_big", bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS,
+                kernel_ms_per_step=k["ms"] / iters, launches_per_step=k["calls"] / iters,
+                algorithmic_flops_per_step=k["flops"], mfma_pipe_busy_fraction_100k_profile=mfma,
+                note="flops = sum c_j^2 of the fronts on the multi-workgroup path; measured FP64 MFMA ceiling on this box 34-46 TFLOP/s (tools/ubench/mfma_f64.hip)")
+
+
 def timed_steps(lib, g, p, K, sync_all, barrier):
     import torch
     barrier(); torch.cuda.synchronize()
@@ -132,7 +150,8 @@ def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iter
         fac_ms = sum(k["ms"] / 2 for k in lp if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big"))
         res.update(parallelism="single GPU", kernels_ms_per_step={k["name"]: round(k["ms"] / 2, 3) for k in lp},
                    nnz_L=st["nnz_L"], sum_cj2=st["flops_factor"], fronts=st["n_fronts"], levels=st["n_levels"],
-                   max_front_rows=st["max_front_rows"], factor_tflops=st["flops_factor"] / (1e-3 * fac_ms) / 1e12)
+                   max_front_rows=st["max_front_rows"], factor_tflops=st["flops_factor"] / (1e-3 * fac_ms) / 1e12,
+                   roofline=big_front_roofline(lp, 2))
         lib.dll.aprilsam_amd_resident_end(g.ptr, p.ptr)
     else:
         from aprilsam_amd.shard import ShardedSolver
@@ -284,6 +303,7 @@ def main():
                 "nnz_L": ls["nnz_L"], "sum_cj2": ls["flops_factor"], "fronts": ls["n_fronts"], "levels": ls["n_levels"],
                 "kernels_ms_per_step": {k["name"]: round(k["ms"] / 3, 4) for k in lp},
                 "factor_tflops": ls["flops_factor"] / (1e-3 * sum(k["ms"] / 3 for k in lp if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big"))) / 1e12,
+                "roofline": big_front_roofline(lp, 3),
             }
             lib.dll.aprilsam_amd_resident_end(g.ptr, p.ptr)
             p.destroy(); g.destroy()
