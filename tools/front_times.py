@@ -28,7 +28,5 @@ for l in range(P.nLevels):
     a = np.array([[T[t, 1] - T[t, 0], T[t, 2] - T[t, 1], T[t, 3] - T[t, 2]] for t in fr])
     span = max(T[t, 3] for t in fr) - min(T[t, 0] for t in fr)
     big = max(fr, key=lambda t: T[t, 3] - T[t, 0])
-    ph = buf[big, 4:8] * 0.01
     print(f"level {l}: {len(fr):4d} fronts  span {span:7.1f} us | mean asm {a[:,0].mean():6.1f} fac {a[:,1].mean():6.1f} store {a[:,2].mean():6.1f} | "
-          f"slowest nsb={P.front_nsb[big]} nub={P.front_nub[big]} nch={P.ch_ptr[big+1]-P.ch_ptr[big]}: asm {T[big,1]-T[big,0]:.1f} fac {T[big,2]-T[big,1]:.1f} store {T[big,3]-T[big,2]:.1f}"
-          f" | panels {int(buf[big,7])}: diag {ph[0]:.1f} rows {ph[1]:.1f} trail {ph[2]:.1f}")
+          f"slowest nsb={P.front_nsb[big]} nub={P.front_nub[big]} nch={P.ch_ptr[big+1]-P.ch_ptr[big]}: asm {T[big,1]-T[big,0]:.1f} fac {T[big,2]-T[big,1]:.1f} store {T[big,3]-T[big,2]:.1f}")
