@@ -323,3 +323,24 @@ def test_lattice_1m_single_gpu_matches_the_recorded_trace(lib):
     got = np.array([chi2[0], chi2[1], chi2[3]]); want = np.array(bench.LATTICE1M_CHI2)
     assert np.max(np.abs(got - want) / want) < 1e-9, (got, want)
     p.destroy(); g.destroy()
+
+
+def test_many_tiny_and_odd_graphs_agree_with_oracle(lib, oracle):
+    """2 .. 45 poses, from a bare chain to nearly complete graphs, several leaf sizes: fronts of one pose, panels narrower
+    than an MFMA k-step, children with a single block, empty update blocks"""
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    try:
+        for trial in range(60):
+            n = int(rng.integers(2, 46))
+            extra = int(rng.integers(0, max(1, n * (n - 1) // 2 - (n - 1)) // (1 if trial % 3 == 0 else 4) + 1))
+            arr = datasets.random_pose_graph(n, extra, 1000 + trial, spread=4.0)
+            lib.set_option("leaf_nodes", [1, 2, 5, 16][trial % 4])
+            oc, ost = oracle.iterate(arr, 2)
+            chi2, snaps, stats = run_batch(lib, arr, 2)
+            assert stats["not_spd"] == 0
+            assert np.max(np.abs(chi2 - oc)) < 1e-8 * max(oc[0], 1e-9), (trial, n, extra, chi2, oc)
+            worst = max(worst, float(np.max(np.abs(snaps[-1][0] - ost))))
+    finally:
+        lib.set_option("leaf_nodes", 16)
+    assert worst < STATE_ATOL
