@@ -344,3 +344,59 @@ def test_many_tiny_and_odd_graphs_agree_with_oracle(lib, oracle):
     finally:
         lib.set_option("leaf_nodes", 16)
     assert worst < STATE_ATOL
+
+
+def _random_growth(lib, rng_seed, steps, nthreshold, old_old=False):
+    """grow a pose graph step by step through the reference API: every step adds 1-2 poses with odometry, often loop
+    closures to random old poses (full information matrices); old_old: sometimes also a factor between two old poses"""
+    rng = np.random.default_rng(rng_seed)
+    g = lib.new_graph(); p = lib.new_param(nthreshold=nthreshold, delta_xy=0.05, delta_theta=0.05)
+    truth = [np.zeros(3)]
+    g.add_node_xyt(truth[0]); g.add_factor_xytpos(0, [0, 0, 0], datasets.PRIOR_W)
+    g.cholesky(p)
+    trace = []
+
+    def rel(a, b):
+        c, s = np.cos(a[2]), np.sin(a[2]); dx, dy = b[0] - a[0], b[1] - a[1]
+        return np.array([c * dx + s * dy, -s * dx + c * dy, b[2] - a[2]])
+
+    def info():
+        M = rng.normal(size=(3, 3)); Wk = M @ M.T + np.diag([40.0, 40.0, 120.0]); return (Wk + Wk.T) / 2
+
+    for step in range(steps):
+        for _ in range(1 + (step % 7 == 3)):
+            last = truth[-1]
+            new = np.array([last[0] + np.cos(last[2]) * 0.8, last[1] + np.sin(last[2]) * 0.8, last[2] + rng.uniform(-0.6, 0.6)])
+            truth.append(new); n = len(truth) - 1
+            g.add_node_xyt(new + rng.normal(0, [0.15, 0.15, 0.04]))
+            g.add_factor_xyt(n - 1, n, rel(truth[n - 1], new) + rng.normal(0, [0.03, 0.03, 0.01]), info())
+        n = len(truth) - 1
+        if n > 4 and rng.random() < 0.6:
+            for _ in range(int(rng.integers(1, 3))):
+                o = int(rng.integers(0, n - 1))
+                a, b = (o, n) if rng.random() < 0.5 else (n, o)
+                g.add_factor_xyt(a, b, rel(truth[a], truth[b]) + rng.normal(0, [0.03, 0.03, 0.01]), info())
+        if old_old and n > 10 and step % 11 == 5:
+            a, b = sorted(rng.choice(n - 1, 2, replace=False).tolist())
+            g.add_factor_xyt(a, b, rel(truth[a], truth[b]) + rng.normal(0, [0.03, 0.03, 0.01]), info())
+        p.c.batch_time = 1e300
+        g.cholesky_inc(p)
+        trace.append((g.chi2(), g.states()))
+    p.destroy(); g.destroy()
+    return trace
+
+
+@pytest.mark.parametrize("seed,nthreshold", [(1, 25), (2, 10 ** 6), (3, 8)])
+def test_random_incremental_growth_matches_the_live_reference(lib, reflib, seed, nthreshold):
+    """irregular incremental use (several poses per call, loop closures in both orientations, frequent or no batch
+    fall-backs) step by step against the unmodified reference: chi^2 and every state.
+    Factors between two OLD poses are left out on purpose: when the two poses sit in different branches of the
+    reference's elimination tree, its partial re-factorisation (aprilsam.c:850-906, children first over the OLD tree)
+    finalises one row before the other has updated it, and its result is no longer the solution of its own system
+    (measured: 3e-2 off the exact solve, this build 1e-4 incl. the prior's relinearisation) -- see
+    test_incremental_general_usage_falls_back_to_replanning for that case against the exact solve."""
+    ours = _random_growth(lib, seed, 140, nthreshold)
+    ref = _random_growth(reflib, seed, 140, nthreshold)
+    for k, ((c1, s1), (c2, s2)) in enumerate(zip(ours, ref)):
+        assert abs(c1 - c2) <= 1e-6 * max(c2, 1.0), (k, c1, c2)
+        assert np.max(np.abs(s1 - s2)) < 1e-6, k
