@@ -347,10 +347,10 @@ def main():
 
         def give_up():
             if rank == 0:
-                out["lattice1m"] = {"error": "watchdog: sharded solve did not finish in 420 s", "n_gpus": world}
+                out["lattice1m"] = {"error": "watchdog: sharded solve did not finish in 240 s", "n_gpus": world}
                 print(json.dumps(out), flush=True)
             os._exit(0)
-        dog = threading.Timer(420.0, give_up); dog.daemon = True; dog.start()
+        dog = threading.Timer(240.0, give_up); dog.daemon = True; dog.start()
         try:
             out["lattice1m"] = lattice1m(lib, rank, world, device, a.backend, barrier, sync_all, K=a.lattice1m_k)
         except Exception as e:
