@@ -116,6 +116,16 @@ aprilsam_amd_plan_t *aprilsam_amd_plan_create(int n_nodes, int n_factors, const 
 }
 void aprilsam_amd_plan_destroy(aprilsam_amd_plan_t *plan) { delete plan; }
 
+// ownership / exchange lists of a `world`-rank sharded run of this plan (host logic only; same code shard_begin uses)
+long long aprilsam_amd_shard_plan(const aprilsam_amd_plan_t *plan, int world, int what, long long *out, long long cap) {
+    if (!plan || world < 1) return -1;
+    std::vector<int> owner; std::vector<char> top; std::vector<long long> xfer, bcast, v;
+    asam::shard_map(plan->P, world, owner, top, xfer, bcast);
+    if (what == 1) v = xfer; else if (what == 2) v = bcast; else if (what == 3) v.assign(owner.begin(), owner.end()); else return -1;
+    if (out) for (long long i = 0; i < (long long)v.size() && i < cap; i++) out[i] = v[i];
+    return (long long)v.size();
+}
+
 long long aprilsam_amd_plan_query(const aprilsam_amd_plan_t *plan, const char *what, long long **out) {
     const asam::Plan &P = plan->P;
     std::vector<long long> v;

@@ -1,5 +1,6 @@
 // solver.h — internal interface between the C-ABI layer (capi.cpp) and the HIP runtime (solver.hip.cpp)
 #pragma once
+#include <vector>
 #include "../../include/aprilsam_amd.h"
 
 namespace asam {
@@ -44,6 +45,8 @@ void shard_end(const april_graph_cholesky_param_t *param);
 int debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts);
 int api_device_count();
 int selftest();
+struct Plan;
+void shard_map(const Plan &P, int world, std::vector<int> &owner, std::vector<char> &top, std::vector<long long> &xfer, std::vector<long long> &bcast);
 int api_set_device(int d);
 int api_set_option(const char *name, double v);
 

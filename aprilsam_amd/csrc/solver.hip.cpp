@@ -1450,21 +1450,11 @@ struct ShardState {
 };
 static std::unordered_map<const void *, std::unique_ptr<ShardState>> g_shard;
 
-int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank, int world) {
-    if (zsize(g->nodes) == 0 || zsize(g->factors) == 0 || world < 1 || rank < 0 || rank >= world) return -1;
-    ensure_device();
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context &c = ctx_for(param);
-    GraphPack &gp = pack_for(g);
-    pack_factors(gp, g);
-    if (!gp.host_idx.empty()) return -4;
-    pack_states(gp, g, false);
-    prepare_plan(c, gp, g);
-    upload_factors(gp);
-    set_lambda(c, gp, param->tikhanov);
-    const Plan &P = c.plan;
-    auto &S = *(g_shard[param] = std::make_unique<ShardState>());
-    S.rank = rank; S.world = world;
+// Ownership of the fronts and the exchange lists of a `world`-rank run: pure host logic on the plan (also reachable
+// without a GPU through aprilsam_amd_shard_plan, tests/test_distributed_cpu.py)
+void shard_map(const Plan &P, int world, std::vector<int> &owner, std::vector<char> &top, std::vector<long long> &xfer, std::vector<long long> &bcast) {
+    struct { std::vector<int> &owner; std::vector<char> &top; std::vector<long long> &xfer, &bcast; } S{ owner, top, xfer, bcast };
+    S.xfer.clear(); S.bcast.clear();
     // subtree work (flops proxy) per front
     std::vector<double> work(P.nF, 0.0);
     for (int t = 0; t < P.nF; t++) {
@@ -1495,6 +1485,34 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
             else { wb += work[ch]; lo[ch] = mid; hi[ch] = hi[t]; }
         }
     }
+    // exchange lists
+    for (int t = 0; t < P.nF; t++) {
+        const int par = P.f_parent[t];
+        if (par >= 0 && S.owner[par] != S.owner[t]) {
+            const long long R = P.rows(t), C = P.cols(t), ns = 3ll * P.f_nsb[t];
+            const long long v[6] = { P.f_level[t], t, S.owner[t], S.owner[par], P.f_off[t], upd_packed_offset((int)R, (int)ns, (int)C) };
+            S.xfer.insert(S.xfer.end(), v, v + 6);
+        }
+        if (S.top[t]) { const long long v[5] = { P.f_level[t], t, S.owner[t], P.f_first[t], P.f_nsb[t] }; S.bcast.insert(S.bcast.end(), v, v + 5); }
+    }
+}
+
+int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank, int world) {
+    if (zsize(g->nodes) == 0 || zsize(g->factors) == 0 || world < 1 || rank < 0 || rank >= world) return -1;
+    ensure_device();
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context &c = ctx_for(param);
+    GraphPack &gp = pack_for(g);
+    pack_factors(gp, g);
+    if (!gp.host_idx.empty()) return -4;
+    pack_states(gp, g, false);
+    prepare_plan(c, gp, g);
+    upload_factors(gp);
+    set_lambda(c, gp, param->tikhanov);
+    const Plan &P = c.plan;
+    auto &S = *(g_shard[param] = std::make_unique<ShardState>());
+    S.rank = rank; S.world = world;
+    shard_map(P, world, S.owner, S.top, S.xfer, S.bcast);
     // launch tables of the owned fronts, appended behind the full tables
     std::vector<int> tab;
     S.levels.assign(P.nLevels, LevelPlan());
@@ -1520,16 +1538,6 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
     S.n_flist = (int)fl.size();
     S.d_flist.need(std::max<size_t>(1, fl.size()));
     if (!fl.empty()) HIPCHECK(hipMemcpyAsync(S.d_flist.p, fl.data(), fl.size() * 4, hipMemcpyHostToDevice, gp.stream));
-    // exchange lists
-    for (int t = 0; t < P.nF; t++) {
-        const int par = P.f_parent[t];
-        if (par >= 0 && S.owner[par] != S.owner[t]) {
-            const long long R = P.rows(t), C = P.cols(t), ns = 3ll * P.f_nsb[t];
-            const long long v[6] = { P.f_level[t], t, S.owner[t], S.owner[par], P.f_off[t], upd_packed_offset((int)R, (int)ns, (int)C) };
-            S.xfer.insert(S.xfer.end(), v, v + 6);
-        }
-        if (S.top[t]) { const long long v[5] = { P.f_level[t], t, S.owner[t], P.f_first[t], P.f_nsb[t] }; S.bcast.insert(S.bcast.end(), v, v + 5); }
-    }
     HIPCHECK(hipMemsetAsync(c.d_x.p, 0, (size_t)24 * gp.N, gp.stream));     // poses of other ranks' subtrees simply do not move here
     HIPCHECK(hipStreamSynchronize(gp.stream));
     c.st.n_nodes = gp.N; c.st.n_factors = gp.F;

@@ -293,6 +293,9 @@ void aprilsam_amd_plan_destroy(aprilsam_amd_plan_t *plan);
  *       "front_rows_ptr", "front_rows" (block positions of every front's rows: own then struct),
  *       "factor_front", "stats" (n_fronts, n_levels, max_rows, nnzL, flops) */
 long long aprilsam_amd_plan_query(const aprilsam_amd_plan_t *plan, const char *what, long long **out);
+/* Ownership map and exchange lists of a `world`-rank sharded run of this plan, as aprilsam_amd_shard_info reports them
+ * (what: 1 transfers x6, 2 broadcasts x5, 3 owner per front); host logic only. */
+long long aprilsam_amd_shard_plan(const aprilsam_amd_plan_t *plan, int world, int what, long long *out, long long cap);
 void aprilsam_amd_free(void *p);
 
 /* Host logic behind the incremental path: the reference's elimination order (aprilsam.c:999-1249, restated

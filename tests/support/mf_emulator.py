@@ -16,7 +16,7 @@ class PlanView:
              "factor_swap", "bd_front_ptr", "bd_row", "bd_col", "bd_src_ptr", "bd_src", "rd_front_ptr", "rd_col",
              "rd_src_ptr", "rd_src", "lev_ptr", "lev_fronts", "stats"]
 
-    def __init__(self, lib, n_nodes, fa, fb, xy=None, leaf_nodes=16):
+    def __init__(self, lib, n_nodes, fa, fb, xy=None, leaf_nodes=16, shard_worlds=()):
         fn = np.ascontiguousarray(np.column_stack([fa, fb]).astype(np.int32))
         xyp = None
         if xy is not None:
@@ -30,6 +30,19 @@ class PlanView:
                 assert n >= 0, name
                 setattr(self, name, np.array(out[:n], dtype=np.int64))
                 lib.dll.aprilsam_amd_free(out)
+            # ownership / exchange lists of sharded runs of this plan (aprilsam_amd_shard_plan), per requested world size
+            self.shard = {}
+            if shard_worlds:
+                lib.dll.aprilsam_amd_shard_plan.restype = C.c_longlong
+                lib.dll.aprilsam_amd_shard_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.c_longlong]
+            for w in shard_worlds:
+                lists = []
+                for what in (1, 2, 3):
+                    n = lib.dll.aprilsam_amd_shard_plan(h, w, what, None, 0)
+                    buf = np.zeros(max(int(n), 1), np.int64)
+                    lib.dll.aprilsam_amd_shard_plan(h, w, what, buf.ctypes.data_as(C.POINTER(C.c_longlong)), n)
+                    lists.append(buf[:n])
+                self.shard[w] = (lists[0].reshape(-1, 6), lists[1].reshape(-1, 5), lists[2])
         finally:
             lib.dll.aprilsam_amd_plan_destroy(h)
         self.N = n_nodes
