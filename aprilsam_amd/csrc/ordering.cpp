@@ -190,15 +190,21 @@ struct Dissector {
         score(comp, out);
     }
 
-    // cost of a split: separator size, with a steep penalty once the larger part exceeds 62 % — on the GPU
-    // the depth of the elimination tree is paid in dependent kernel launches, so balance beats a few poses
+    // cost of a split: separator size, with a penalty once the larger part exceeds 62 % — on the GPU the depth of the
+    // elimination tree is paid in dependent kernel launches, so balance beats a few poses.  The weights were tuned against
+    // the iteration time of M3500 through a per-level cost model of the kernels (tools/nd_tune.py): lowering the quadratic
+    // term from 400 to 100 alone took M3500 from 0.53 to 0.43 ms per iteration (sum over levels of the widest supernode
+    // 151 -> 131 poses) and left the lattices unchanged.  APRILSAM_AMD_ND_* override them for experiments.
     void score(const std::vector<int> &comp, Split &out) {
         out.ok = !out.P0.empty() && !out.P1.empty() && !out.S.empty();
         if (out.ok) {
             double n = (double)comp.size() - (double)out.S.size();
             double imb = std::max(out.P0.size(), out.P1.size()) / n;       // 0.5 .. 1
-            double over = std::max(0.0, imb - 0.62);
-            out.cost = (double)out.S.size() * (1.0 + 25.0 * over) + 400.0 * over * over * (double)comp.size();
+            static const double T_IMB = getenv("APRILSAM_AMD_ND_IMB") ? atof(getenv("APRILSAM_AMD_ND_IMB")) : 0.62;         // tuning knobs (defaults measured on M3500)
+            static const double T_LIN = getenv("APRILSAM_AMD_ND_LIN") ? atof(getenv("APRILSAM_AMD_ND_LIN")) : 25.0;
+            static const double T_QUAD = getenv("APRILSAM_AMD_ND_QUAD") ? atof(getenv("APRILSAM_AMD_ND_QUAD")) : 100.0;
+            double over = std::max(0.0, imb - T_IMB);
+            out.cost = (double)out.S.size() * (1.0 + T_LIN * over) + T_QUAD * over * over * (double)comp.size();
         }
     }
 
@@ -320,11 +326,21 @@ struct Dissector {
     template <class Stack>
     void handle(std::vector<int> &comp, int L, int parent, Stack &stack) {
         if ((int)comp.size() <= leaf) { for (int v : comp) set_lab(v, -1); new_node(std::move(comp), parent); return; }
-        Split cand[4];
+        Split cand[8];
         split_geometric(comp, L, cand[0]);
-        if ((int)comp.size() > 8 * leaf) {                              // the extra directions only pay near the top of the tree
+        static const int T_DIRS = getenv("APRILSAM_AMD_ND_DIRS") ? atoi(getenv("APRILSAM_AMD_ND_DIRS")) : 8;
+        static const int T_REF = getenv("APRILSAM_AMD_ND_REF") ? atoi(getenv("APRILSAM_AMD_ND_REF")) : 4;
+        static const int T_BAND = getenv("APRILSAM_AMD_ND_BAND") ? atoi(getenv("APRILSAM_AMD_ND_BAND")) : 2;
+        if ((int)comp.size() > T_DIRS * leaf) {                         // the extra directions only pay near the top of the tree
             split_geometric(comp, L, cand[1], 1.5707963267948966);      // orthogonal axis
             split_geometric(comp, L, cand[2], 0.7853981633974483);      // diagonal
+        }
+        static const int T_MORE = getenv("APRILSAM_AMD_ND_MORE") ? atoi(getenv("APRILSAM_AMD_ND_MORE")) : 0;      // region size (x leaf) above which 4 more directions are tried
+        if (T_MORE > 0 && (int)comp.size() > T_MORE * leaf) {
+            split_geometric(comp, L, cand[4], 2.356194490192345);       // other diagonal
+            split_geometric(comp, L, cand[5], 0.39269908169872414);
+            split_geometric(comp, L, cand[6], 1.1780972450961724);
+            split_geometric(comp, L, cand[7], 1.9634954084936207);
         }
         split_bfs(comp, L, cand[3]);
         Split *best = nullptr, *second = nullptr;
@@ -333,10 +349,10 @@ struct Dissector {
             if (!best || c.cost < best->cost) { second = best; best = &c; }
             else if (!second || c.cost < second->cost) second = &c;
         }
-        if (best && (int)comp.size() > 4 * leaf) {
+        if (best && (int)comp.size() > T_REF * leaf) {
             for (Split *c : { best, second }) {
                 if (!c || (c == second && second->cost > 1.25 * best->cost)) continue;
-                for (int pass = 0; pass < 2; pass++) { double before = c->cost; refine_band(comp, L, *c, 2); if (c->cost >= before) break; }
+                for (int pass = 0; pass < 2; pass++) { double before = c->cost; refine_band(comp, L, *c, T_BAND); if (c->cost >= before) break; }
             }
             if (second && second->cost < best->cost) best = second;
         }
