@@ -70,6 +70,13 @@ class ShardedSolver:
         if not to_lib and not self.on_gpu:
             self.buf[:cnt].copy_(self.dbuf[:cnt])
 
+    def _comm_done(self):
+        """With RCCL a collective / send / recv returns once it is ENQUEUED (the wait only chains the current torch stream
+        behind the communication stream).  The library packs and unpacks on its own HIP stream, which torch knows nothing
+        about, so the host has to wait for the communication before the buffer is read or overwritten."""
+        if self.on_gpu:
+            self.torch.cuda.current_stream().synchronize()
+
     def iterate(self, n=1):
         dist = self.dist
         for _ in range(n):
@@ -79,9 +86,9 @@ class ShardedSolver:
                 for _, front, src, dst, off, cnt in self.up[l]:
                     if self.rank == src:
                         self._copy(2, front, cnt, False)
-                        dist.send(self.buf[:cnt], dst=int(dst))
+                        dist.send(self.buf[:cnt], dst=int(dst)); self._comm_done()
                     elif self.rank == dst:
-                        dist.recv(self.buf[:cnt], src=int(src))
+                        dist.recv(self.buf[:cnt], src=int(src)); self._comm_done()
                         self._copy(2, front, cnt, True)
             for l in range(self.n_levels - 1, -1, -1):
                 self._step(2, l)
@@ -89,7 +96,7 @@ class ShardedSolver:
                     cnt = 3 * int(nsb)
                     if self.rank == owner:
                         self._copy(1, 3 * int(first), cnt, False)
-                    dist.broadcast(self.buf[:cnt], src=int(owner))
+                    dist.broadcast(self.buf[:cnt], src=int(owner)); self._comm_done()
                     if self.rank != owner:
                         self._copy(1, 3 * int(first), cnt, True)
             self._step(3)
@@ -100,7 +107,7 @@ class ShardedSolver:
     def chi2(self):
         t = self.torch.tensor([self.lib.dll.aprilsam_amd_shard_chi2_local(self._g, self._p)], dtype=self.torch.float64, device=self.dev)
         self.dist.all_reduce(t)
-        return float(t.item())
+        return float(t.item())          # .item() synchronises
 
     def comm_bytes_per_iteration(self):
         return int(8 * (self.xfer[:, 5].sum() + 3 * self.bcast[:, 4].sum() * (self.world - 1)))
