@@ -14,7 +14,8 @@ struct Options {
     int small_lds_kb = 156;       // fronts whose LDS image fits run in the single-workgroup LDS kernel
     int inc_fast = 1;             // incremental steps regenerate only the dirty root paths (0: full re-plan per step)
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
-    int small_threads = 512;      // workgroup size of k_front_small (256 / 512 / 1024)
+    int small_threads = 1024;     // workgroup size of k_front_small (256 / 512 / 1024) on latency-bound levels ...
+    int tp_threads = 512;         // ... and on throughput levels (>= tp_fronts fronts)
     int tp_fronts = 1000;         // levels with at least this many fronts are "throughput levels" ...
     int tp_lds_kb = 64;           // ... where only fronts up to this LDS size run fully in LDS (the rest: panel mode, more workgroups per CU)
     int lookahead = 0;            // 1: wide trailing updates split, next outer block columns first, the rest on a side stream (measured: no gain)

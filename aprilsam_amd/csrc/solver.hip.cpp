@@ -65,6 +65,7 @@ static void load_env_options() {
         v = g_opt.small_threads; envd("APRILSAM_AMD_SMALL_THREADS", &v); g_opt.small_threads = (int)v;
         v = g_opt.tp_fronts; envd("APRILSAM_AMD_TP_FRONTS", &v); g_opt.tp_fronts = (int)v;
         v = g_opt.tp_lds_kb; envd("APRILSAM_AMD_TP_LDS_KB", &v); g_opt.tp_lds_kb = (int)v;
+        v = g_opt.tp_threads; envd("APRILSAM_AMD_TP_THREADS", &v); g_opt.tp_threads = (int)v;
         v = g_opt.lookahead; envd("APRILSAM_AMD_LOOKAHEAD", &v); g_opt.lookahead = (int)v;
         v = g_opt.inc_fast; envd("APRILSAM_AMD_INC_FAST", &v); g_opt.inc_fast = (int)v;
     });
@@ -289,6 +290,7 @@ struct Launch { int list_off, pre_off, n, grid; bool single = false; int tile = 
 struct LevelPlan {
     int small_off = 0, n_small = 0; size_t small_lds = 0;      // fronts handled by k_front_small
     long long full_limit = 0;                                  // ... fully in LDS when their array fits this many bytes, else panel mode
+    int small_nt = 512;                                        // ... with this many threads per workgroup
     int n_big = 0; size_t asm_lds = 0;
     Launch asm_big{};                                          // k_assemble_big
     std::vector<Launch> syrka, syrkb;                          // look-ahead split of the wide update (modes 2, 3), same indexing as syrkw
@@ -404,7 +406,10 @@ constexpr int INC_NODES = 4096, INC_FACT = 16384, INC_I32 = 4 << 20, INC_DEST = 
 constexpr long long INC_POOL_MIN = 64ll << 20;            // doubles (512 MB)
 
 // waves of a k_front_small workgroup (option small_threads)
-static int small_waves() { return g_opt.small_threads >= 1024 ? 16 : (g_opt.small_threads >= 512 ? 8 : 4); }
+static int waves_of(int nt) { return nt >= 1024 ? 16 : (nt >= 512 ? 8 : 4); }
+// workgroup size of k_front_small on a level with n fronts: latency levels take the big workgroup (more lanes on one
+// front's critical path), throughput levels the smaller one (more workgroups per CU)
+static int small_threads_for(size_t n_fronts) { return (int)n_fronts >= g_opt.tp_fronts ? std::min(g_opt.small_threads, g_opt.tp_threads) : g_opt.small_threads; }
 
 // classify the fronts of one level (small / big) and append their launch tables to `tab`
 template <class Dims>
@@ -421,10 +426,12 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     size_t full_max = small_max;
     if ((int)fronts.size() >= g_opt.tp_fronts && g_opt.tp_lds_kb > 0) full_max = std::min(small_max, (size_t)g_opt.tp_lds_kb * 1024);
     L.full_limit = (long long)full_max;
+    L.small_nt = small_threads_for(fronts.size());
+    const int nw = waves_of(L.small_nt);
     for (int t : fronts) {
         const int R = rows(t), C = cols(t);
         maxm = std::max<size_t>(maxm, C);
-        const size_t lds_s = small_front_lds(R, C, small_waves()), lds_p = panel_front_lds(R, 3 * nsb_of(t), small_waves());
+        const size_t lds_s = small_front_lds(R, C, nw), lds_p = panel_front_lds(R, 3 * nsb_of(t), nw);
         if (lds_s <= full_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); }
         else if (g_opt.panel_mode && lds_p <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_p); }   // k_front_small, panel mode
         else if (lds_s <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); L.full_limit = std::max(L.full_limit, (long long)lds_s); }
@@ -584,7 +591,7 @@ static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic 
 
 // k_front_small with the configured workgroup size (option small_threads: 256 / 512 / 1024)
 static void launch_front_small(Context &c, const LevelPlan &L, hipStream_t s) {
-    const int nt = g_opt.small_threads;
+    const int nt = L.small_nt;
     if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit);
     else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit);
     else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit);
@@ -1399,7 +1406,8 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
         const double ns = 3.0 * P.f_nsb[t], nu = 3.0 * P.f_nub[t], R = P.rows(t), C = P.cols(t);
         double fl = 0;                                          // sum_j c_j^2 over this front's columns (+ rhs row)
         for (int q = 0; q < (int)ns; q++) { double cj = (ns - q) + nu + 1; fl += cj * cj; }
-        const bool small = small_front_lds((int)R, (int)C, small_waves()) <= small_max || (g_opt.panel_mode && panel_front_lds((int)R, (int)ns, small_waves()) <= small_max);
+        const int nwp = waves_of(small_threads_for((size_t)(P.lev_ptr[P.f_level[t] + 1] - P.lev_ptr[P.f_level[t]])));
+        const bool small = small_front_lds((int)R, (int)C, nwp) <= small_max || (g_opt.panel_mode && panel_front_lds((int)R, (int)ns, nwp) <= small_max);
         // algorithmic bytes of a front: its L panel + update block written once, children's updates read once
         const double by = 8.0 * (ns * (ns + 1) / 2 + (nu + 1) * ns + (nu + 1) * (nu + 2) / 2);
         if (small) { flops[K_FRONT_SMALL] += fl; bytes[K_FRONT_SMALL] += by; }
@@ -1729,6 +1737,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "small_threads") g_opt.small_threads = (int)v;
     else if (k == "tp_fronts") g_opt.tp_fronts = (int)v;
     else if (k == "tp_lds_kb") g_opt.tp_lds_kb = (int)v;
+    else if (k == "tp_threads") g_opt.tp_threads = (int)v;
     else if (k == "lookahead") g_opt.lookahead = (int)v;
     else if (k == "inc_fast") g_opt.inc_fast = (int)v;
     else return -1;

@@ -231,7 +231,8 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *   "tp_fronts", "tp_lds_kb"  levels with at least tp_fronts fronts (default 1000) are throughput-bound: there only
  *                       fronts up to tp_lds_kb KiB (default 64) run fully in LDS, larger ones use panel mode so that
  *                       several workgroups share a compute unit
- *   "small_threads"     workgroup size of the single-workgroup front kernel: 256 / 512 / 1024 (default 512)
+ *   "small_threads", "tp_threads"  workgroup size of the single-workgroup front kernel (256 / 512 / 1024) on
+ *                       latency-bound levels (default 1024) and on throughput levels (default 512)
  *   "syrk128_rows"      trailing updates at least this tall use the LDS-staged 128x128 MFMA kernel (default off)
  *   "inc_fast"          0 = every incremental step re-plans (default 1: frozen base plan + dirty root paths) */
 int aprilsam_amd_set_option(const char *name, double value);
