@@ -68,6 +68,7 @@ static void load_env_options() {
         v = g_opt.tp_threads; envd("APRILSAM_AMD_TP_THREADS", &v); g_opt.tp_threads = (int)v;
         v = g_opt.lookahead; envd("APRILSAM_AMD_LOOKAHEAD", &v); g_opt.lookahead = (int)v;
         v = g_opt.inc_fast; envd("APRILSAM_AMD_INC_FAST", &v); g_opt.inc_fast = (int)v;
+        v = g_opt.block_factor; envd("APRILSAM_AMD_BLOCK_FACTOR", &v); g_opt.block_factor = (int)v;
     });
 }
 
@@ -535,8 +536,8 @@ static void upload_plan(Context &c, hipStream_t s) {
     d.f_rows = c.d_i32.p; d.f_rel = c.d_i32.p; d.slot_blk = c.d_i32.p + o_sb; d.slot_rhs = c.d_i32.p + o_sr; d.src_idx = c.d_i32.p;
     c.inc.o_rows = (long long)o_rows; c.inc.o_rel = (long long)o_rel;
     d.lambda = c.d_lambda.p;
-    d.prof = nullptr;
-    if (getenv("APRILSAM_AMD_KPROF")) { c.d_prof.need((size_t)8 * P.nF); HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)64 * P.nF, s)); d.prof = c.d_prof.p; }
+    d.prof = nullptr; d.prof_mode = 0;
+    if (getenv("APRILSAM_AMD_KPROF")) { c.d_prof.need((size_t)PROF_SLOTS * P.nF); HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)8 * PROF_SLOTS * P.nF, s)); d.prof = c.d_prof.p; d.prof_mode = atoi(getenv("APRILSAM_AMD_KPROF")) == 2 ? 2 : 1; }
     c.d_swap.need((size_t)P.F + INC_FACT); c.d_pos.need((size_t)P.N + INC_NODES);
     HIPCHECK(hipMemcpyAsync(c.d_swap.p, P.fac_swap.data(), P.F, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_pos.p, P.pos.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
@@ -592,9 +593,9 @@ static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic 
 // k_front_small with the configured workgroup size (option small_threads: 256 / 512 / 1024)
 static void launch_front_small(Context &c, const LevelPlan &L, hipStream_t s) {
     const int nt = L.small_nt;
-    if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit);
-    else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit);
-    else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit);
+    if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
+    else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
+    else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
 }
 
 // panel steps of the big fronts of one level: per NB-column panel {diagonal block, row solves, narrow update};
@@ -689,7 +690,7 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     };
     auto toc = [&]() { if (ktime) { HIPCHECK(hipEventRecord(c.k_ev[nev + 1], s)); nev += 2; } };
     if (ev) HIPCHECK(hipEventRecord(ev[0], s));
-    if (c.dp.prof) HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)64 * P.nF, s));
+    if (c.dp.prof) HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)8 * PROF_SLOTS * P.nF, s));
     tic(K_LINEARIZE);
     hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                        gp.d_lp.p, unary_at_lp ? gp.d_lp.p : gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p);
@@ -1431,7 +1432,7 @@ int debug_front_times(const april_graph_cholesky_param_t *param, long long *out,
     if (it == g_ctx.end() || !it->second->d_prof.p) return -1;
     HIPCHECK(hipDeviceSynchronize());
     int n = std::min(n_fronts, it->second->plan.nF);
-    HIPCHECK(hipMemcpy(out, it->second->d_prof.p, (size_t)64 * n, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(out, it->second->d_prof.p, (size_t)8 * PROF_SLOTS * n, hipMemcpyDeviceToHost));
     return n;
 }
 // ------------------------------------------------------------------------------------------------------
@@ -1740,6 +1741,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "tp_threads") g_opt.tp_threads = (int)v;
     else if (k == "lookahead") g_opt.lookahead = (int)v;
     else if (k == "inc_fast") g_opt.inc_fast = (int)v;
+    else if (k == "block_factor") g_opt.block_factor = (int)v;
     else return -1;
     return 0;
 }

@@ -323,7 +323,7 @@ int aprilsam_amd_lattice_arrays(int K, double *states, int *fa, int *fb, double 
 void aprilsam_amd_graph_from_arrays(april_graph_t *graph, int N, const double *states, int F, const int *fa,
                                     const int *fb, const double *z, const double *W);
 
-/* debug (env APRILSAM_AMD_KPROF=1): 8 wall-clock stamps (100 MHz ticks) per front from the last numeric pass */
+/* debug (env APRILSAM_AMD_KPROF=1): 16 wall-clock stamps (100 MHz ticks) per front from the last numeric pass */
 int aprilsam_amd_debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts);
 
 const char *aprilsam_amd_version(void);

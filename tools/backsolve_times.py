@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, "/root/repo")
-os.environ["APRILSAM_AMD_KPROF"] = "1"
+os.environ["APRILSAM_AMD_KPROF"] = "2"
 from aprilsam_amd import datasets, host
 from tests.support.mf_emulator import PlanView
 lib = host.SolverLib()
@@ -11,7 +11,7 @@ g = lib.new_graph(); g.build_from_arrays(*arr); p = lib.new_param()
 lib.set_option("use_graph", 0)
 for _ in range(3): g.cholesky(p)
 nF = p.stats()["n_fronts"]
-buf = np.zeros((nF, 8), np.int64)
+buf = np.zeros((nF, 16), np.int64)
 lib.dll.aprilsam_amd_debug_front_times(p.ptr, buf.ctypes.data_as(C.POINTER(C.c_longlong)), nF)
 P = PlanView(lib, len(arr[0]), arr[1], arr[2], xy=arr[0][:, :2], leaf_nodes=16)
 for l in range(P.nLevels - 1, -1, -1):
