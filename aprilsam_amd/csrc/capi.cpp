@@ -63,6 +63,7 @@ int aprilsam_amd_resident_end(april_graph_t *graph, april_graph_cholesky_param_t
 int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls, double *flops, double *bytes, const char **names) {
     return asam::kernel_profile(param, ms, calls, flops, bytes, names);
 }
+int aprilsam_amd_debug_stage(april_graph_t *graph, april_graph_cholesky_param_t *param, int what, double *out) { return asam::debug_stage(graph, param, what, out); }
 int aprilsam_amd_debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts) { return asam::debug_front_times(param, out, n_fronts); }
 // host logic, no GPU: the reference's elimination order (aprilsam.c:999-1249 restated) and block elimination
 // tree for a graph given as factor endpoint arrays; out_order / out_parent: n_nodes ints each
@@ -75,11 +76,12 @@ int aprilsam_amd_reference_order(int n_nodes, int n_factors, const int *fa, cons
 }
 int aprilsam_amd_shard_begin(april_graph_t *graph, april_graph_cholesky_param_t *param, int rank, int world) { return asam::shard_begin(graph, param, rank, world); }
 long long aprilsam_amd_shard_info(const april_graph_cholesky_param_t *param, int what, long long *out, long long cap) { return asam::shard_info(param, what, out, cap); }
-int aprilsam_amd_shard_step(april_graph_t *graph, april_graph_cholesky_param_t *param, int op, int arg) { return asam::shard_step(graph, param, op, arg); }
-int aprilsam_amd_shard_copy(april_graph_t *graph, april_graph_cholesky_param_t *param, int kind, long long offset, long long count, void *buf, int dir) {
-    return asam::shard_copy(graph, param, kind, offset, count, buf, dir);
-}
-double aprilsam_amd_shard_chi2_local(april_graph_t *graph, april_graph_cholesky_param_t *param) { return asam::shard_chi2_local(graph, param); }
+int aprilsam_amd_shard_comm_unique_id(char *out128) { return asam::shard_comm_unique_id(out128); }
+int aprilsam_amd_shard_comm_init_rccl(april_graph_cholesky_param_t *param, const char *id128) { return asam::shard_comm_init_rccl(param, id128); }
+int aprilsam_amd_shard_comm_init_host(april_graph_cholesky_param_t *param, const aprilsam_amd_host_comm_t *cb) { return asam::shard_comm_init_host(param, cb); }
+int aprilsam_amd_shard_iterate(april_graph_t *graph, april_graph_cholesky_param_t *param, int n) { return asam::shard_iterate(graph, param, n); }
+int aprilsam_amd_shard_gather_states(april_graph_t *graph, april_graph_cholesky_param_t *param) { return asam::shard_gather_states(graph, param); }
+double aprilsam_amd_shard_chi2(april_graph_t *graph, april_graph_cholesky_param_t *param) { return asam::shard_chi2(graph, param); }
 void aprilsam_amd_shard_end(april_graph_cholesky_param_t *param) { asam::shard_end(param); }
 
 // test handle on the bookkeeping model (host logic only)

@@ -10,7 +10,7 @@ struct Options {
     int deterministic = 1;        // 1: the wall-clock fallback rule aprilsam.c:557 is disabled
     int use_graph = 1;            // replay the numeric phase from a captured hipGraph
     int device_timing = 0;        // record HIP events per stage (disables graph replay for that call)
-    int trust_factor_cache = 1;   // z/W of factors already packed are treated as immutable
+    int trust_factor_cache = 0;   // 1: z/W of factors already packed are treated as immutable (skips the per-call content check)
     int small_lds_kb = 156;       // fronts whose LDS image fits run in the single-workgroup LDS kernel
     int inc_fast = 1;             // incremental steps regenerate only the dirty root paths (0: full re-plan per step)
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
@@ -40,10 +40,14 @@ void drop_graph_pack(const april_graph_t *g);
 bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out);
 int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank, int world);
 long long shard_info(const april_graph_cholesky_param_t *param, int what, long long *out, long long cap);
-int shard_step(april_graph_t *g, april_graph_cholesky_param_t *param, int op, int arg);
-int shard_copy(april_graph_t *g, april_graph_cholesky_param_t *param, int kind, long long offset, long long count, void *buf, int dir);
-double shard_chi2_local(april_graph_t *g, april_graph_cholesky_param_t *param);
+int shard_comm_unique_id(char *out128);
+int shard_comm_init_rccl(const april_graph_cholesky_param_t *param, const char *id128);
+int shard_comm_init_host(const april_graph_cholesky_param_t *param, const aprilsam_amd_host_comm_t *cb);
+int shard_iterate(april_graph_t *g, april_graph_cholesky_param_t *param, int n);
+int shard_gather_states(april_graph_t *g, april_graph_cholesky_param_t *param);
+double shard_chi2(april_graph_t *g, april_graph_cholesky_param_t *param);
 void shard_end(const april_graph_cholesky_param_t *param);
+int debug_stage(april_graph_t *g, april_graph_cholesky_param_t *param, int what, double *out);
 int debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts);
 int api_device_count();
 int selftest();

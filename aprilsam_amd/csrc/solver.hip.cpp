@@ -5,8 +5,11 @@
 //
 // Reference call stack this replaces: aprilsam.c:87-375 (april_graph_cholesky) — see SURVEY.md §3.1.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -129,6 +132,10 @@ struct GraphPack {
     DBuf<int> d_fa, d_fb;
     DBuf<double> d_z, d_W, d_state, d_lp, d_dx, d_chi2f, d_scalar;
     int F_on_device = 0;               // factors already uploaded
+    int dirty_lo = 0, dirty_hi = 0;    // packed factors whose z / W changed since the last upload
+    long long content_version = 0;     // bumped whenever z / W of a packed factor changed
+    std::vector<char> is_host;         // per factor: evaluated on the host through factor->eval
+    std::vector<double> h_upt; DBuf<double> d_upt;   // unary factors: the state they were linearised at when they entered the system (3 per factor)
     int F_cap = 0;                     // device capacity (factors) of d_fa/d_fb/d_z/d_W/d_chi2f
     // factors of foreign types, evaluated on the host through factor->eval: indices, 33 doubles each
     // (Haa, Hab, Hbb, ga, gb), how many of them hold a current evaluation
@@ -138,7 +145,7 @@ struct GraphPack {
     void release() {
         h_fa.release(); h_fb.release(); h_z.release(); h_W.release(); h_state.release(); h_lp.release(); h_dx.release();
         d_fa.release(); d_fb.release(); d_z.release(); d_W.release(); d_state.release(); d_lp.release(); d_dx.release();
-        d_chi2f.release(); d_scalar.release(); h_scalar.release(); h_hostH.release(); d_hostH.release(); d_host_idx.release();
+        d_chi2f.release(); d_scalar.release(); h_scalar.release(); h_hostH.release(); d_hostH.release(); d_host_idx.release(); d_upt.release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -164,33 +171,67 @@ void drop_graph_pack(const april_graph_t *g) {
 
 static inline int zsize(const zarray_t *z) { return z ? z->size : 0; }
 
-// (re)pack factors [from, F): ids, z, W.  Unknown factor types are fatal (no host-fallback vtable yet).
+// (re)pack the factors: ids, z, W into the pinned SoA mirror.  The reference re-reads every factor object on every call
+// (aprilsam.c:152-190, april_graph.c:79-98), so by default every already-packed factor is compared with the mirror
+// (nodes, z, W: 104 bytes) and only what changed is copied and uploaded again; a changed endpoint or factor kind
+// restarts the pack.  Option trust_factor_cache = 1 skips the comparison for factors whose object pointer is unchanged
+// (z / W of a packed factor are then treated as immutable).
 static void pack_factors(GraphPack &gp, const april_graph_t *g) {
     const int F = zsize(g->factors);
     april_graph_factor_t **fs = (april_graph_factor_t **)g->factors->data;
-    int from = gp.F;
-    bool valid = g_opt.trust_factor_cache && from <= F && (int)gp.fptr.size() == from &&
-                 (from == 0 || memcmp(gp.fptr.data(), fs, sizeof(void *) * from) == 0);
-    if (!valid) { from = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; }
-    gp.h_fa.need(F, true); gp.h_fb.need(F, true); gp.h_z.need((size_t)3 * F, true); gp.h_W.need((size_t)9 * F, true);
-    gp.fptr.resize(F);
     const int N = zsize(g->nodes);
-    for (int i = from; i < F; i++) {
-        const april_graph_factor_t *f = fs[i];
-        gp.fptr[i] = f;
-        int a = -1, b = -1;
+    int from = gp.F;
+    bool valid = from <= F && (int)gp.fptr.size() == from;
+    if (valid && g_opt.trust_factor_cache) valid = from == 0 || memcmp(gp.fptr.data(), fs, sizeof(void *) * from) == 0;
+    if (!valid) { from = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; gp.is_host.clear(); }
+    gp.h_fa.need(F, true); gp.h_fb.need(F, true); gp.h_z.need((size_t)3 * F, true); gp.h_W.need((size_t)9 * F, true);
+    gp.fptr.resize(F); gp.is_host.resize(F, 0);
+    auto classify = [&](const april_graph_factor_t *f, int i, int *a, int *b) -> bool {      // returns host_eval
         bool host_eval = false;
-        if (f->type == APRIL_GRAPH_FACTOR_XYT_TYPE && f->nnodes == 2) { a = f->nodes[0]; b = f->nodes[1]; }
-        else if (f->type == APRIL_GRAPH_FACTOR_XYTPOS_TYPE && f->nnodes == 1) { a = f->nodes[0]; b = -1; }
+        *a = -1; *b = -1;
+        if (f->type == APRIL_GRAPH_FACTOR_XYT_TYPE && f->nnodes == 2) { *a = f->nodes[0]; *b = f->nodes[1]; }
+        else if (f->type == APRIL_GRAPH_FACTOR_XYTPOS_TYPE && f->nnodes == 1) { *a = f->nodes[0]; *b = -1; }
         else if ((f->nnodes == 1 || f->nnodes == 2) && f->eval) {     // any other type: the factor's own eval(), on the host
-            a = f->nodes[0]; b = f->nnodes == 2 ? f->nodes[1] : -1; host_eval = true;
+            *a = f->nodes[0]; *b = f->nnodes == 2 ? f->nodes[1] : -1; host_eval = true;
         } else {
             fprintf(stderr, "aprilsam_amd: FATAL: factor %d has type %d / %d nodes; factors of foreign types are supported with one or "
                             "two nodes and an eval() function pointer (aprilsam.h:110-122)\n", i, f->type, f->nnodes);
             abort();
         }
-        if (a < 0 || a >= N || b >= N || a == b) { fprintf(stderr, "aprilsam_amd: FATAL: factor %d references node out of range\n", i); abort(); }
-        gp.h_fa.p[i] = a; gp.h_fb.p[i] = b;
+        if (*a < 0 || *a >= N || *b >= N || *a == *b) { fprintf(stderr, "aprilsam_amd: FATAL: factor %d references node out of range\n", i); abort(); }
+        return host_eval;
+    };
+    if (from > 0 && !g_opt.trust_factor_cache) {
+        // content check of the packed prefix; dirty range [lo, hi) is uploaded again by upload_factors
+        int lo = from, hi = 0;
+        bool restart = false;
+        for (int i = 0; i < from; i++) {
+            if (i + 8 < from) __builtin_prefetch(fs[i + 8]);
+            const april_graph_factor_t *f = fs[i];
+            int a, b;
+            const bool host_eval = classify(f, i, &a, &b);
+            if (a != gp.h_fa.p[i] || b != gp.h_fb.p[i] || host_eval != (bool)gp.is_host[i]) { restart = true; break; }
+            gp.fptr[i] = f;
+            if (host_eval) continue;
+            double *zp = gp.h_z.p + (size_t)3 * i, *Wp = gp.h_W.p + (size_t)9 * i;
+            if (memcmp(zp, f->u.common.z, 24) != 0 || memcmp(Wp, f->u.common.W->data, 72) != 0) {
+                memcpy(zp, f->u.common.z, 24); memcpy(Wp, f->u.common.W->data, 72);
+                lo = std::min(lo, i); hi = std::max(hi, i + 1);
+            }
+        }
+        if (restart) { from = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; }
+        else if (hi > lo) {
+            if (gp.dirty_hi > gp.dirty_lo) { gp.dirty_lo = std::min(gp.dirty_lo, lo); gp.dirty_hi = std::max(gp.dirty_hi, hi); }
+            else { gp.dirty_lo = lo; gp.dirty_hi = hi; }
+            gp.content_version++;
+        }
+    }
+    for (int i = from; i < F; i++) {
+        const april_graph_factor_t *f = fs[i];
+        gp.fptr[i] = f;
+        int a, b;
+        const bool host_eval = classify(f, i, &a, &b);
+        gp.h_fa.p[i] = a; gp.h_fb.p[i] = b; gp.is_host[i] = host_eval;
         if (host_eval) {          // the device kernels see a null factor (W = 0) in its place; k_scatter_host fills its slots
             memset(gp.h_z.p + (size_t)3 * i, 0, 24); memset(gp.h_W.p + (size_t)9 * i, 0, 72);
             gp.host_idx.push_back(i);
@@ -217,6 +258,12 @@ static void upload_factors(GraphPack &gp) {
         HIPCHECK(hipMemcpyAsync(gp.d_z.p + (size_t)3 * f0, gp.h_z.p + (size_t)3 * f0, n * 24, hipMemcpyHostToDevice, gp.stream));
         HIPCHECK(hipMemcpyAsync(gp.d_W.p + (size_t)9 * f0, gp.h_W.p + (size_t)9 * f0, n * 72, hipMemcpyHostToDevice, gp.stream));
     }
+    const int d0 = gp.dirty_lo, d1 = std::min(gp.dirty_hi, f0);      // z / W of packed factors edited in place by the caller
+    if (d1 > d0) {
+        HIPCHECK(hipMemcpyAsync(gp.d_z.p + (size_t)3 * d0, gp.h_z.p + (size_t)3 * d0, (size_t)(d1 - d0) * 24, hipMemcpyHostToDevice, gp.stream));
+        HIPCHECK(hipMemcpyAsync(gp.d_W.p + (size_t)9 * d0, gp.h_W.p + (size_t)9 * d0, (size_t)(d1 - d0) * 72, hipMemcpyHostToDevice, gp.stream));
+    }
+    gp.dirty_lo = gp.dirty_hi = 0;
     gp.F_on_device = F;
     gp.d_scalar.need(8); gp.h_scalar.need(8);
 }
@@ -265,11 +312,12 @@ static void upload_host_index(GraphPack &gp) {
 }
 
 // states (and l_points) of all nodes -> pinned host -> device
-static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp) {
+static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp, bool upload = true) {
     const int N = zsize(g->nodes);
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
     gp.h_state.need((size_t)3 * N); gp.h_lp.need((size_t)3 * N); gp.h_dx.need((size_t)3 * N);
     for (int i = 0; i < N; i++) {
+        if (i + 8 < N) __builtin_prefetch(ns[i + 8]->state);
         const april_graph_node_t *n = ns[i];
         if (n->type != APRIL_GRAPH_NODE_XYT_TYPE || n->length != 3) fatal("only xyt nodes (type 100, 3 DoF) are supported (aprilsam.h:94)");
         memcpy(gp.h_state.p + (size_t)3 * i, n->state, 24);
@@ -277,8 +325,16 @@ static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp) {
     }
     gp.N = N;
     gp.d_state.need((size_t)3 * N); gp.d_lp.need((size_t)3 * N); gp.d_dx.need((size_t)3 * N);
+    if (!upload) return;          // (the batch step reads the pinned mirror from its first kernel, k_load_states)
     HIPCHECK(hipMemcpyAsync(gp.d_state.p, gp.h_state.p, (size_t)24 * N, hipMemcpyHostToDevice, gp.stream));
     if (with_lp) HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.h_lp.p, (size_t)24 * N, hipMemcpyHostToDevice, gp.stream));
+}
+
+// evaluation points of the unary factors [from, to): the node's state as packed by this call (april_graph_xytpos.c:83-85
+// reads node->state when the factor is evaluated, and the reference evaluates a factor exactly once between batch steps)
+static void record_unary_points(GraphPack &gp, int from, int to, const double *states) {
+    gp.h_upt.resize((size_t)3 * gp.F, 0.0);
+    for (int f = from; f < to; f++) if (gp.h_fb.p[f] < 0) memcpy(&gp.h_upt[(size_t)3 * f], states + (size_t)3 * gp.h_fa.p[f], 24);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -305,6 +361,7 @@ struct LevelPlan {
 struct IncState {
     bool ready = false;                     // helper tables below are built for the current base plan
     int Nb = 0, Fb = 0, nF0 = 0, nLev0 = 0;
+    int cap_nodes = 0, cap_fact = 0;         // slack reserved at plan upload (0 until the param has seen an incremental call)
     long long i32_used = 0, dest_used = 0, child_used = 0, tab_used = 0, pool_used = 0, pool_cap = 0, o_rows = 0, o_rel = 0;
     int slots_used = 0;
     std::vector<FrontDesc> fd;              // host mirror of the device descriptors (base fronts, then TAIL)
@@ -350,6 +407,7 @@ struct Context {
     std::vector<hipEvent_t> k_ev; std::vector<int> k_ids;
     // incremental bookkeeping (aprilsam.c:741-751, 566-575)
     bool have_fact = false;               // a batch factorisation exists (reference: param->chol != NULL)
+    bool want_inc = false;                // the param has been used incrementally: plan uploads reserve the append slack
     int batch_nodes = 0;                  // #nodes at the last batch step (those carry the Tikhonov term)
     IncState inc;
     int inc_F = 0, inc_N = 0;                      // factors / nodes folded into the factorisation so far
@@ -367,11 +425,18 @@ struct Context {
     // captured numeric phase
     hipGraphExec_t gexec = nullptr;
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
+    // the same phase as the API call runs it: first kernel reads the caller's states from the pinned mirror, last kernel
+    // writes new states / dx / pivot flag back to pinned mirrors -- one graph launch + one stream sync per call
+    hipGraphExec_t gexec_api = nullptr;
+    const void *api_key[6] = {};
+    double lambda_val = -1; int lambda_N = -1;     // what d_lambda currently holds (uniform batch value), -1: unknown
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
         d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release();
         if (gexec) (void)hipGraphExecDestroy(gexec);
         gexec = nullptr;
+        if (gexec_api) (void)hipGraphExecDestroy(gexec_api);
+        gexec_api = nullptr;
         if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
         have_events = false;
         for (auto &e : k_ev) (void)hipEventDestroy(e);
@@ -404,7 +469,7 @@ bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out)
 
 // slack reserved at plan upload so that the incremental path can append without reallocating device buffers
 constexpr int INC_NODES = 4096, INC_FACT = 16384, INC_I32 = 4 << 20, INC_DEST = 1 << 20, INC_CHILD = 1 << 18, INC_TAB = 1 << 20;
-constexpr long long INC_POOL_MIN = 64ll << 20;            // doubles (512 MB)
+constexpr long long INC_POOL_MIN = 8ll << 20;             // doubles (64 MB; the M3500 demo appends ~25 MB of regenerated fronts between two batch steps)
 
 // waves of a k_front_small workgroup (option small_threads)
 static int waves_of(int nt) { return nt >= 1024 ? 16 : (nt >= 512 ? 8 : 4); }
@@ -492,17 +557,24 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     }
 }
 
+// Per-rank layout of the front pool in a sharded run: a rank keeps the frontal arrays of the fronts it OWNS and, for
+// every child of an owned front that lives on another rank, a "ghost" holding only that child's update block
+// ((3 cnu + 3) rows x 3 cnu columns: what the parent's extend-add reads, filled from the wire).  off < 0: not present.
+struct ShardLayout { std::vector<long long> off; std::vector<char> ghost; long long pool_doubles = 0; };
+
 // upload the symbolic plan and build the per-level launch tables
-static void upload_plan(Context &c, hipStream_t s) {
+static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = nullptr) {
     const Plan &P = c.plan;
     if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
+    if (c.gexec_api) { (void)hipGraphExecDestroy(c.gexec_api); c.gexec_api = nullptr; }
+    c.lambda_N = -1;
     // ---- descriptors + index arrays ----------------------------------------------------------------------------
     std::vector<FrontDesc> &fd = c.inc.fd; fd.assign(P.nF, FrontDesc());
     std::vector<ChildRec> ch(std::max<size_t>(1, P.ch_idx.size()));
     for (int t = 0; t < P.nF; t++) {
         FrontDesc &d = fd[t];
         memset(&d, 0, sizeof(d));
-        d.off = P.f_off[t]; d.nsb = P.f_nsb[t]; d.nub = P.f_nub[t]; d.first = P.f_first[t];
+        d.off = lay ? std::max<long long>(lay->off[t], 0) : P.f_off[t]; d.nsb = P.f_nsb[t]; d.nub = P.f_nub[t]; d.first = P.f_first[t];
         d.dest_begin = P.dest_front_ptr[t]; d.dest_end = P.dest_front_ptr[t + 1];
         d.ch_begin = P.ch_ptr[t]; d.ch_end = P.ch_ptr[t + 1];
         d.rows_begin = 0; d.parent = P.f_parent[t];      // rows_begin patched below (absolute offset in the int arena)
@@ -512,24 +584,34 @@ static void upload_plan(Context &c, hipStream_t s) {
         ChildRec &r = ch[k];
         r.cR = P.rows(cfr); r.cnu = P.f_nub[cfr];
         r.uoff = P.f_off[cfr] + (long long)(3 * P.f_nsb[cfr]) * r.cR + 3 * P.f_nsb[cfr];
+        if (lay) {
+            if (lay->ghost[cfr]) { r.cR = 3 * r.cnu + 3; r.uoff = lay->off[cfr]; }
+            else r.uoff = std::max<long long>(lay->off[cfr], 0) + (long long)(3 * P.f_nsb[cfr]) * r.cR + 3 * P.f_nsb[cfr];
+        }
         r.rel_begin = 0; r.pad = cfr;                  // rel_begin patched below; pad keeps the child's front id
     }
+    // slack for the incremental path is only reserved once the param has been used incrementally (a 3-node tutorial graph
+    // solved in batch mode should not cost hundreds of MB of HBM); the first incremental call then re-plans once
+    const bool inc = c.want_inc;
+    const int INC_NODES_ = inc ? INC_NODES : 0, INC_FACT_ = inc ? INC_FACT : 0;
+    const size_t INC_I32_ = inc ? INC_I32 : 0, INC_DEST_ = inc ? INC_DEST : 0, INC_CHILD_ = inc ? INC_CHILD : 0, INC_TAB_ = inc ? INC_TAB : 0;
+    c.inc.cap_nodes = INC_NODES_; c.inc.cap_fact = INC_FACT_;
     std::vector<int> i32;
     auto put32 = [&](const std::vector<int> &v) { size_t o = i32.size(); i32.insert(i32.end(), v.begin(), v.end()); if (v.empty()) i32.push_back(0); return o; };
     size_t o_rows = put32(P.f_rows), o_rel = put32(P.f_rel);
-    size_t o_sb = put32(P.slot_blk); i32.resize(i32.size() + (size_t)3 * INC_FACT, -1);      // room for factors added incrementally
-    size_t o_sr = put32(P.slot_rhs); i32.resize(i32.size() + (size_t)2 * INC_FACT, -1);
+    size_t o_sb = put32(P.slot_blk); i32.resize(i32.size() + (size_t)3 * INC_FACT_, -1);      // room for factors added incrementally
+    size_t o_sr = put32(P.slot_rhs); i32.resize(i32.size() + (size_t)2 * INC_FACT_, -1);
     c.inc.i32_used = (long long)i32.size(); c.inc.dest_used = (long long)P.dest.size(); c.inc.child_used = (long long)P.ch_idx.size();
     for (int t = 0; t < P.nF; t++) fd[t].rows_begin = (int)(o_rows + P.f_rows_ptr[t]);
     for (size_t k = 0; k < P.ch_idx.size(); k++) ch[k].rel_begin = (int)(o_rel + P.f_rows_ptr[ch[k].pad]);
-    c.d_i32.need(i32.size() + INC_I32); c.d_fd.need(fd.size() + 1); c.d_child.need(ch.size() + INC_CHILD);
-    c.d_dest.need(std::max<size_t>(1, P.dest.size()) + INC_DEST);
+    c.d_i32.need(i32.size() + INC_I32_); c.d_fd.need(fd.size() + 1); c.d_child.need(ch.size() + INC_CHILD_);
+    c.d_dest.need(std::max<size_t>(1, P.dest.size()) + INC_DEST_);
     HIPCHECK(hipMemcpyAsync(c.d_i32.p, i32.data(), i32.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_fd.p, fd.data(), fd.size() * sizeof(FrontDesc), hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_child.p, ch.data(), ch.size() * sizeof(ChildRec), hipMemcpyHostToDevice, s));
     static_assert(sizeof(DestRec) == sizeof(Plan::DestRec), "DestRec layout");
     if (!P.dest.empty()) HIPCHECK(hipMemcpyAsync(c.d_dest.p, P.dest.data(), P.dest.size() * sizeof(DestRec), hipMemcpyHostToDevice, s));
-    c.d_lambda.need((size_t)P.N + INC_NODES);
+    c.d_lambda.need((size_t)P.N + INC_NODES_);
     DevPlan &d = c.dp;
     d.nF = P.nF;
     d.fd = c.d_fd.p; d.dest = c.d_dest.p; d.child = c.d_child.p;
@@ -538,7 +620,7 @@ static void upload_plan(Context &c, hipStream_t s) {
     d.lambda = c.d_lambda.p;
     d.prof = nullptr; d.prof_mode = 0;
     if (getenv("APRILSAM_AMD_KPROF")) { c.d_prof.need((size_t)PROF_SLOTS * P.nF); HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)8 * PROF_SLOTS * P.nF, s)); d.prof = c.d_prof.p; d.prof_mode = atoi(getenv("APRILSAM_AMD_KPROF")) == 2 ? 2 : 1; }
-    c.d_swap.need((size_t)P.F + INC_FACT); c.d_pos.need((size_t)P.N + INC_NODES);
+    c.d_swap.need((size_t)P.F + INC_FACT_); c.d_pos.need((size_t)P.N + INC_NODES_);
     HIPCHECK(hipMemcpyAsync(c.d_swap.p, P.fac_swap.data(), P.F, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_pos.p, P.pos.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
 
@@ -549,23 +631,28 @@ static void upload_plan(Context &c, hipStream_t s) {
         std::vector<int> fr(P.lev_fronts.begin() + P.lev_ptr[l], P.lev_fronts.begin() + P.lev_ptr[l + 1]);
         build_level(c.levels[l], fr, tab, [&](int t, int *nsb, int *nub) { *nsb = P.f_nsb[t]; *nub = P.f_nub[t]; });
     }
+    for (int l = 0; l < P.nLevels; l++)
+        if (c.levels[l].solve_lds > 160 * 1024)       // k_backsolve keeps x over a front's rows in LDS (~19 000 scalar rows)
+            fatal("a frontal matrix has more rows than the back-substitution kernel can hold in LDS (an unsplittable dense region "
+                  "of more than ~6000 poses); this build does not tile the solve of such a front");
     if (tab.empty()) tab.push_back(0);
-    c.d_tab.need(tab.size() + INC_TAB);
+    c.d_tab.need(tab.size() + INC_TAB_);
     c.inc.tab_used = (long long)tab.size();
     c.base_tab = tab;
     HIPCHECK(hipMemcpyAsync(c.d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipStreamSynchronize(s));      // host vectors above go out of scope
 
-    const long long pool_slack = std::max<long long>(INC_POOL_MIN, P.pool_doubles / 4);
-    c.d_pool.need((size_t)std::max<int64_t>(P.pool_doubles, 1) + (size_t)pool_slack);
-    c.inc.pool_used = P.pool_doubles; c.inc.pool_cap = (long long)c.d_pool.cap;
-    c.d_H.need((size_t)9 * ((size_t)std::max(1, P.n_slots) + (size_t)5 * INC_FACT)); c.d_x.need((size_t)3 * ((size_t)P.N + INC_NODES));
+    const long long pool_slack = inc ? std::max<long long>(INC_POOL_MIN, P.pool_doubles / 4) : 0;
+    const long long pool_doubles = lay ? lay->pool_doubles : P.pool_doubles;
+    c.d_pool.need((size_t)std::max<long long>(pool_doubles, 1) + (size_t)pool_slack);
+    c.inc.pool_used = pool_doubles; c.inc.pool_cap = (long long)c.d_pool.cap;
+    c.d_H.need((size_t)9 * ((size_t)std::max(1, P.n_slots) + (size_t)5 * INC_FACT_)); c.d_x.need((size_t)3 * ((size_t)P.N + INC_NODES_));
     c.inc.slots_used = P.n_slots;
     c.inc.ready = false;
     c.d_bad.need(4); c.h_bad.need(4);
     { int mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, c.levels[l].n_big); c.d_diag.need((size_t)(mx + 64) * NB * (NB + 1)); }
     c.st.n_fronts = P.nF; c.st.n_levels = P.nLevels; c.st.max_front_rows = P.max_rows;
-    c.st.nnz_L = P.nnzL; c.st.flops_factor = P.flops; c.st.bytes_fronts = 8.0 * (double)P.pool_doubles;
+    c.st.nnz_L = P.nnzL; c.st.flops_factor = P.flops; c.st.bytes_fronts = 8.0 * (double)pool_doubles;
 }
 
 static void set_small_attr() {
@@ -580,33 +667,36 @@ static void set_small_attr() {
 
 // back substitution of one level: update-row products of the large fronts on many workgroups, then one workgroup per front
 template <class Tic, class Toc>
-static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc) {
+static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, const int *tab = nullptr) {
+    if (!tab) tab = c.d_tab.p;
     if (!L.n_all) return;
     tic(K_BACKSOLVE);
     if (L.bs_gemv.grid > 0)
-        hipLaunchKernelGGL(k_backsolve_gemv, dim3(L.bs_gemv.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + L.bs_gemv.list_off, c.d_tab.p + L.bs_gemv.pre_off,
+        hipLaunchKernelGGL(k_backsolve_gemv, dim3(L.bs_gemv.grid), dim3(TPB), 0, s, c.dp, tab + L.bs_gemv.list_off, tab + L.bs_gemv.pre_off,
                            L.bs_gemv.n, c.d_pool.p, c.d_x.p);
-    hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0);
     toc();
 }
 
 // k_front_small with the configured workgroup size (option small_threads: 256 / 512 / 1024)
-static void launch_front_small(Context &c, const LevelPlan &L, hipStream_t s) {
+static void launch_front_small(Context &c, const LevelPlan &L, hipStream_t s, const int *tab = nullptr) {
+    if (!tab) tab = c.d_tab.p;
     const int nt = L.small_nt;
-    if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
-    else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
-    else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, c.d_tab.p + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
+    if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
+    else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
+    else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
 }
 
 // panel steps of the big fronts of one level: per NB-column panel {diagonal block, row solves, narrow update};
 // after every OBP panels one wide update with K = OBP * NB (kernels.hip.h: syrk_range)
 template <class Tic, class Toc>
-static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, bool la = false) {
+static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, bool la = false, const int *tab = nullptr) {
+    if (!tab) tab = c.d_tab.p;
     auto wide = [&](const Launch &w, int k, int mode, hipStream_t st) {
         if (w.tile == TILE2)
-            hipLaunchKernelGGL(k_syrk_big128, dim3(w.grid), dim3(TPB), 0, st, c.dp, c.d_tab.p + w.list_off, c.d_tab.p + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
+            hipLaunchKernelGGL(k_syrk_big128, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
         else
-            hipLaunchKernelGGL(k_syrk_big, dim3(w.grid), dim3(TPB), 0, st, c.dp, c.d_tab.p + w.list_off, c.d_tab.p + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
+            hipLaunchKernelGGL(k_syrk_big, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
     };
     if (la && !c.s2) {        // lowest priority: its big kernels must not delay the one-workgroup kernels of the chain
         int lo = 0, hi = 0;
@@ -618,19 +708,19 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
         const Launch &pa = L.panel[k], &sy = L.syrk[k], &sw = L.syrkw[k];
         if (pa.single) {          // one row tile per front: diagonal block + row solves in one launch
             tic(K_PANEL_BIG);
-            hipLaunchKernelGGL(k_diagpanel_big, dim3(pa.n), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_bad.p);
+            hipLaunchKernelGGL(k_diagpanel_big, dim3(pa.n), dim3(TPB), 0, s, c.dp, tab + pa.list_off, (int)k, c.d_pool.p, c.d_bad.p);
             toc();
         } else {
             tic(K_DIAG_BIG);
-            hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, c.d_tab.p + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
+            hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, tab + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
             toc();
             tic(K_PANEL_BIG);
-            hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + pa.list_off, c.d_tab.p + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
+            hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, tab + pa.list_off, tab + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
             toc();
         }
         if (sy.grid > 0) {
             tic(K_SYRK_BIG);
-            hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, c.d_tab.p + sy.list_off, c.d_tab.p + sy.pre_off, sy.n, (int)k, (int)k + 1, 0, c.d_pool.p);
+            hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, tab + sy.list_off, tab + sy.pre_off, sy.n, (int)k, (int)k + 1, 0, c.d_pool.p);
             toc();
         }
         if (!la) {
@@ -659,25 +749,26 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
 
 // kernels of one level of the factorisation (small LDS fronts, big multi-workgroup path)
 template <class Tic, class Toc>
-static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, bool la = false) {
+static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, bool la = false, const int *tab = nullptr) {
+    if (!tab) tab = c.d_tab.p;
     if (L.n_small) {
         tic(K_FRONT_SMALL);
-        launch_front_small(c, L, s);
+        launch_front_small(c, L, s, tab);
         toc();
     }
     if (L.n_big) {
         tic(K_ASSEMBLE_BIG);
-        hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
-                           c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
+        hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, tab + L.asm_big.list_off,
+                           tab + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
         toc();
-        enqueue_big_steps(c, L, s, tic, toc, la);
+        enqueue_big_steps(c, L, s, tic, toc, la, tab);
     }
 }
 
 // enqueue: linearise -> per level {assemble+factor} -> back substitution -> state update
 // ev != null: record stage events (0 start, 1 after linearise, 2 after factor, 3 after solve+update)
 // ktime: bracket EVERY kernel launch with its own HIP event pair on this stream (c.k_ev / c.k_ids)
-static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t *ev, bool unary_at_lp = false, bool ktime = false) {
+static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t *ev, bool unary_at_lp = false, bool ktime = false, bool io_host = false) {
     const Plan &P = c.plan;
     const int F = P.F, N = P.N;
     size_t nev = 0;
@@ -691,9 +782,10 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     auto toc = [&]() { if (ktime) { HIPCHECK(hipEventRecord(c.k_ev[nev + 1], s)); nev += 2; } };
     if (ev) HIPCHECK(hipEventRecord(ev[0], s));
     if (c.dp.prof) HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)8 * PROF_SLOTS * P.nF, s));
+    if (io_host) hipLaunchKernelGGL(k_load_states, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.d_state.p, gp.d_lp.p);
     tic(K_LINEARIZE);
     hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                       gp.d_lp.p, unary_at_lp ? gp.d_lp.p : gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p);
+                       gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, unary_at_lp ? gp.d_upt.p : (const double *)nullptr);
     if (!gp.host_idx.empty()) {         // host-evaluated factors: their blocks replace the null contributions written above
         const int nh = (int)gp.host_idx.size();
         HIPCHECK(hipMemcpyAsync(gp.d_hostH.p, gp.h_hostH.p, (size_t)33 * 8 * nh, hipMemcpyHostToDevice, s));
@@ -709,7 +801,10 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
         launch_backsolve(c, c.levels[l], s, tic, toc);
     }
     tic(K_UPDATE);
-    hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
+    if (io_host) hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
+                                    gp.h_lp.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);
+    else hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
+                            (double *)nullptr, (double *)nullptr, (const int *)nullptr, (int *)nullptr);
     toc();
     if (ev) HIPCHECK(hipEventRecord(ev[3], s));
     HIPCHECK(hipGetLastError());
@@ -725,10 +820,29 @@ static void collect_kernel_times(Context &c) {
 }
 
 // run the numeric phase, replaying a captured hipGraph when enabled
-static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp = false) {
+static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp = false, bool io_host = false) {
     hipStream_t s = gp.stream;
     set_small_attr();
     if (timing && !c.have_events) { for (auto &e : c.ev) HIPCHECK(hipEventCreate(&e)); c.have_events = true; }
+    if (io_host) {
+        if (g_opt.use_graph && !timing && gp.host_idx.empty()) {
+            const void *key[6] = { gp.d_state.p, gp.h_state.p, gp.h_lp.p, gp.h_dx.p, c.h_bad.p, (const void *)(size_t)gp.N };
+            if (!c.gexec_api || memcmp(key, c.api_key, sizeof(key)) != 0) {
+                if (c.gexec_api) { (void)hipGraphExecDestroy(c.gexec_api); c.gexec_api = nullptr; }
+                hipGraph_t graph = nullptr;
+                HIPCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                enqueue_numeric(c, gp, s, nullptr, false, false, true);
+                HIPCHECK(hipStreamEndCapture(s, &graph));
+                HIPCHECK(hipGraphInstantiate(&c.gexec_api, graph, nullptr, nullptr, 0));
+                HIPCHECK(hipGraphDestroy(graph));
+                memcpy(c.api_key, key, sizeof(key));
+            }
+            HIPCHECK(hipGraphLaunch(c.gexec_api, s));
+        } else {
+            enqueue_numeric(c, gp, s, timing ? c.ev : nullptr, false, false, true);
+        }
+        return;
+    }
     if (g_opt.use_graph && !timing && !unary_at_lp && gp.host_idx.empty()) {   // (host-evaluated factors: staging buffers may move)
         if (!c.gexec || c.gexec_key != (const void *)gp.d_state.p) {
             if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
@@ -757,7 +871,7 @@ static double device_chi2(GraphPack &gp) {     // chi^2 at d_state; synchronises
 }
 
 // make sure plan / device buffers match the packed graph; returns true if the plan was reused
-static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g) {
+static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g, bool upload = true) {
     const int N = gp.N, F = gp.F;
     bool same = c.have_plan && c.patN == N && (int)c.pat.size() == 2 * F && c.plan.leaf_nodes == g_opt.leaf_nodes;
     if (same) {
@@ -772,7 +886,7 @@ static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g) {
     const double tb0 = now_ms();
     build_plan(c.plan, N, F, c.pat.data(), xy.data(), g_opt.leaf_nodes);
     const double tb1 = now_ms();
-    upload_plan(c, gp.stream);
+    if (upload) upload_plan(c, gp.stream);
     if (getenv("APRILSAM_AMD_PLAN_PROFILE")) fprintf(stderr, "aprilsam_amd plan: N=%d build %.3f ms upload %.3f ms\n", N, tb1 - tb0, now_ms() - tb1);
     c.have_plan = true;
     return false;
@@ -812,7 +926,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     IncState &I = c.inc; Plan &P = c.plan;
     if (!I.ready || N < I.Nb || Fold < I.Fb) return false;
     const int Nb = I.Nb, nF0 = I.nF0, TAIL = nF0, m = N - Nb;
-    if (m > INC_NODES - 8 || F - I.Fb > INC_FACT - 8 || m < 1) return false;
+    if (m > I.cap_nodes - 8 || F - I.Fb > I.cap_fact - 8 || m < 1) return false;
     const int *fa = gp.h_fa.p, *fb = gp.h_fb.p;
     hipStream_t s = gp.stream;
     auto local_base = [&](int t, int p) -> int {      // local block index of base position p in base front t, or -1
@@ -1006,7 +1120,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 16, s));
     if (F > Fold)
         hipLaunchKernelGGL(k_linearize, dim3((F - Fold + TPB - 1) / TPB), dim3(TPB), 0, s, Fold, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                           gp.d_lp.p, gp.d_lp.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
+                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);      // new priors: at the node's current state
     for (int l = 0; l <= I.nLev0; l++) {
         if (lev_dirty[l].empty()) continue;
         const LevelPlan &L = dl[l];
@@ -1040,6 +1154,8 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
 
 static void set_lambda(Context &c, GraphPack &gp, double lambda) {
     const int N = c.plan.N;
+    if (c.lambda_N == N && c.lambda_val == lambda) return;       // d_lambda already holds it (warm calls)
+    c.lambda_N = N; c.lambda_val = lambda;
     c.h_lambda.assign(N, lambda > 0 ? lambda : 0.0);            // aprilsam.c:197-204
     HIPCHECK(hipMemcpyAsync(c.d_lambda.p, c.h_lambda.data(), (size_t)8 * N, hipMemcpyHostToDevice, gp.stream));
 }
@@ -1052,8 +1168,9 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     GraphPack &gp = pack_for(g);
     const double t0 = now_ms();
     pack_factors(gp, g);
-    pack_states(gp, g, false);
+    pack_states(gp, g, false, false);
     const int N = gp.N, F = gp.F;
+    c.h_bad.need(4); gp.h_dx.need((size_t)3 * N);
     if (!gp.host_idx.empty()) {       // foreign factor types: their eval() reads the host objects, which the reference
         april_graph_node_t **hn = (april_graph_node_t **)g->nodes->data;     // re-linearises first (aprilsam.c:131-135)
         for (int i = 0; i < N; i++) memcpy(hn[i]->l_point, hn[i]->state, 24);
@@ -1064,15 +1181,13 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     const bool reused = prepare_plan(c, gp, g);
     const double t2 = now_ms();
     upload_factors(gp);
-    // batch: every node is re-linearised first (aprilsam.c:131-135): l_point <- state, on the device
-    HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, gp.stream));
     set_lambda(c, gp, param->tikhanov);
     const double t3 = now_ms();
     const bool timing = g_opt.device_timing != 0;
-    run_numeric(c, gp, timing);
-    HIPCHECK(hipMemcpyAsync(gp.h_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));   // new states
-    HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
-    HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, gp.stream));
+    // One graph launch: k_load_states pulls the packed states from the pinned mirror (state and, every node being
+    // re-linearised first, aprilsam.c:131-135, l_point), ..., k_update_states leaves new states (h_lp), dx and the pivot
+    // flag in pinned mirrors.  No copy-engine call on the path.
+    run_numeric(c, gp, timing, false, true);
     HIPCHECK(hipStreamSynchronize(gp.stream));
     const double t4 = now_ms();
     c.st.not_spd = c.h_bad.p[0] != 0;
@@ -1100,6 +1215,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         param->factor_num = F;
         c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = false;
         inc_prepare(c); c.inc_F = F; c.inc_N = N;
+        record_unary_points(gp, 0, F, gp.h_state.p);         // the linearisation point of this call
         if (param->delta_x) {                                                // aprilsam.c:363-366
             free(param->delta_x);
             param->delta_x = (double *)calloc((size_t)3 * N, sizeof(double));
@@ -1135,7 +1251,8 @@ void batch_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
 // incremental step (aprilsam.c:377-576).  The linear system the reference maintains by partial un-/re-
 // factorisation — every factor linearised at its nodes' l_point (aprilsam.c:508-542; l_points only move in
 // a batch step), Tikhonov term only on poses present at the last batch step (aprilsam.c:197-204 vs :508-542)
-// — is solved on the GPU (round 1: re-assembled and re-factorised in full); WHICH poses receive the result,
+// — is solved on the GPU (only the fronts on the root paths of the new factors are re-assembled and re-factorised,
+// inc_fast_step); WHICH poses receive the result,
 // the relinearisation counter and the batch fall-back follow the reference exactly through the bookkeeping
 // model of refmodel.cpp (measured: on the poses it touches, the reference's result is the exact solution).
 // ------------------------------------------------------------------------------------------------------
@@ -1161,6 +1278,7 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     ensure_device();
     Context &c = ctx_for(param);
     GraphPack &gp = pack_for(g);
+    c.want_inc = true;
     const double t0 = now_ms();
     pack_factors(gp, g);
     pack_states(gp, g, true);
@@ -1175,12 +1293,15 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
         upload_host_index(gp);
     }
     const double tp3 = now_ms();
+    record_unary_points(gp, c.inc_F, F, gp.h_state.p);  // priors added by this call are evaluated at their node's state now
     // fast path: frozen base plan + TAIL front, only the dirty root paths are regenerated and re-factorised
     std::vector<RefModel::Visit> &visits = c.visits;
     c.model.plan_visit(visits);                      // structural: which poses the reference's solve_node touches
     const bool partial = c.model.naffected <= 5;     // aprilsam.c:755: otherwise the whole tree is walked
     bool reused = g_opt.inc_fast && gp.host_idx.empty() && inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, partial ? &visits : nullptr);
     if (!reused) {                // the step does not fit the frozen structure (or slack ran out): full re-plan
+        gp.d_upt.need((size_t)3 * F);
+        HIPCHECK(hipMemcpyAsync(gp.d_upt.p, gp.h_upt.data(), (size_t)24 * F, hipMemcpyHostToDevice, gp.stream));
         prepare_plan(c, gp, g);
         c.h_lambda.assign(N, 0.0);
         for (int i = 0; i < N; i++) if (c.plan.perm[i] < c.batch_nodes && param->tikhanov > 0) c.h_lambda[i] = param->tikhanov;
@@ -1378,6 +1499,7 @@ int resident_end(april_graph_t *g, april_graph_cholesky_param_t *param) {
     param->nreordering = N; param->factor_num = F;
     c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = false;
     inc_prepare(c); c.inc_F = F; c.inc_N = N;
+    record_unary_points(gp, 0, F, gp.h_lp.p);                // (unary factors were last linearised at the final l_points)
     return 0;
 }
 int batch_resident(april_graph_t *g, april_graph_cholesky_param_t *param, int iters, double *chi2_out, double *ms_out) {
@@ -1425,6 +1547,81 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
     return NKERN;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// stage-level parity exports (plan items 1-2): what the device linearisation and the gather
+// assembly produce, in the caller's node coordinates, for comparison with the reference's own J / r / A / B
+// ------------------------------------------------------------------------------------------------------
+// what = 0: per factor 33 doubles -- (J_a^T W) J_a (symmetric, full), (J_a^T W) J_b (rows a, columns b), (J_b^T W) J_b,
+//           (J_a^T W) r, (J_b^T W) r -- read back from the contribution slots k_linearize wrote (out: 33 * F)
+// what = 1: the assembled normal equations A = sum J^T W J + lambda I (dense symmetric (3N)^2, row-major) and
+//           B = sum J^T W r (3N) in NODE coordinates, from the per-destination sums of the assembly's own source lists
+//           (out: 9 N^2 + 3 N doubles; N <= 2000)
+int debug_stage(april_graph_t *g, april_graph_cholesky_param_t *param, int what, double *out) {
+    if (zsize(g->nodes) == 0 || zsize(g->factors) == 0) return -1;
+    ensure_device();
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context &c = ctx_for(param);
+    GraphPack &gp = pack_for(g);
+    pack_factors(gp, g);
+    if (!gp.host_idx.empty()) return -4;
+    pack_states(gp, g, false);
+    prepare_plan(c, gp, g);
+    upload_factors(gp);
+    const Plan &P = c.plan;
+    const int N = gp.N, F = gp.F;
+    hipStream_t s = gp.stream;
+    HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
+                       gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, (const double *)nullptr);
+    if (what == 0) {
+        std::vector<double> H((size_t)9 * std::max(1, P.n_slots));
+        HIPCHECK(hipMemcpyAsync(H.data(), c.d_H.p, H.size() * 8, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        for (int f = 0; f < F; f++) {
+            double *o = out + (size_t)33 * f;
+            memset(o, 0, 33 * 8);
+            memcpy(o, &H[(size_t)9 * P.slot_blk[3 * f]], 72);
+            memcpy(o + 27, &H[(size_t)9 * P.slot_rhs[2 * f]], 24);
+            if (gp.h_fb.p[f] < 0) continue;
+            const double *b1 = &H[(size_t)9 * P.slot_blk[3 * f + 1]];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) o[9 + i * 3 + j] = P.fac_swap[f] ? b1[j * 3 + i] : b1[i * 3 + j];
+            memcpy(o + 18, &H[(size_t)9 * P.slot_blk[3 * f + 2]], 72);
+            memcpy(o + 30, &H[(size_t)9 * P.slot_rhs[2 * f + 1]], 24);
+        }
+        return 0;
+    }
+    if (what != 1 || N > 2000) return -2;
+    const int nd = (int)P.dest.size();
+    DBuf<double> d_out; d_out.need((size_t)9 * std::max(1, nd));
+    hipLaunchKernelGGL(k_debug_dest, dim3((9 * nd + TPB - 1) / TPB), dim3(TPB), 0, s, nd, c.dp.dest, c.dp.src_idx, c.d_H.p, d_out.p);
+    std::vector<double> D((size_t)9 * std::max(1, nd));
+    HIPCHECK(hipMemcpyAsync(D.data(), d_out.p, D.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    d_out.release();
+    const size_t n = (size_t)3 * N;
+    double *A = out, *B = out + n * n;
+    memset(out, 0, (n * n + n) * 8);
+    for (int t = 0; t < P.nF; t++) {
+        auto node_of = [&](int lb) { const int pos = lb < P.f_nsb[t] ? P.f_first[t] + lb : P.f_rows[P.f_rows_ptr[t] + lb - P.f_nsb[t]]; return P.perm[pos]; };
+        for (int d = P.dest_front_ptr[t]; d < P.dest_front_ptr[t + 1]; d++) {
+            const Plan::DestRec &r = P.dest[d];
+            const double *v = &D[(size_t)9 * d];
+            const int nc = node_of(r.bcol);
+            if (r.brow < 0) { for (int j = 0; j < 3; j++) B[(size_t)3 * nc + j] += v[j]; continue; }
+            const int nr = node_of(r.brow);
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    if (r.brow == r.bcol && i < j) continue;          // diagonal blocks: the assembly takes the lower part
+                    const size_t rr = (size_t)3 * nr + i, cc = (size_t)3 * nc + j;
+                    A[rr * n + cc] += v[i * 3 + j];
+                    if (rr != cc) A[cc * n + rr] += v[i * 3 + j];
+                }
+        }
+    }
+    for (size_t i = 0; i < n; i++) A[i * n + i] += param->tikhanov > 0 ? param->tikhanov : 0.0;      // aprilsam.c:197-204
+    return 0;
+}
+
 // debug: copy the per-front clock stamps (8 per front) written when APRILSAM_AMD_KPROF is set
 int debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1448,14 +1645,97 @@ int debug_front_times(const april_graph_cholesky_param_t *param, long long *out,
 // The library only provides the per-level compute steps and the slab copies; the exchange itself is done by the
 // host driver with RCCL through torch.distributed (aprilsam_amd/shard.py) — one process per GPU.
 // ------------------------------------------------------------------------------------------------------
+// ---- transports -----------------------------------------------------------------------------------------------
+// RCCL (librccl.so, loaded at run time: point-to-point send / recv of the Schur slabs, broadcast of the separator
+// solutions, all enqueued on the solver's own HIP stream -- no host synchronisation between a level's kernels and its
+// exchange) or host callbacks (the caller moves pinned host buffers with whatever it has: the tests use gloo, a C host
+// could use MPI); the schedule above them is the same.
+struct Transport {
+    virtual ~Transport() {}
+    virtual void group_begin() {}
+    virtual void group_end() {}
+    virtual void send(const double *dev, long long n, int dst, hipStream_t s) = 0;
+    virtual void recv(double *dev, long long n, int src, hipStream_t s) = 0;
+    virtual void bcast(double *dev, long long n, int root, hipStream_t s) = 0;
+    virtual void allreduce_sum(double *dev, long long n, hipStream_t s) = 0;
+    virtual const char *name() const = 0;
+};
+
+struct RcclApi {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr; decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr; decltype(&ncclSend) Send = nullptr; decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr; decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load() {
+        if (h) return true;
+        // the RCCL that belongs to the HIP runtime THIS library runs on: same directory as the libamdhip64 we are linked to.
+        // (A process may hold a second ROCm stack -- PyTorch wheels bundle their own libamdhip64 / librccl -- and a
+        // communicator created by that one cannot take our streams.)  Plain sonames only as a fall-back.
+        std::string dir;
+        Dl_info di;
+        if (dladdr((const void *)&hipStreamSynchronize, &di) && di.dli_fname) { dir = di.dli_fname; const size_t k = dir.rfind('/'); dir = k == std::string::npos ? "" : dir.substr(0, k + 1); }
+        const std::string cand[] = { dir + "librccl.so.1", dir + "librccl.so", "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so" };
+        for (const std::string &nm : cand) { if (nm.empty()) continue; h = dlopen(nm.c_str(), RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        if (!h) return false;
+#define RCCL_SYM(x) x = (decltype(x))dlsym(h, "nccl" #x); if (!x) return false
+        RCCL_SYM(GetUniqueId); RCCL_SYM(CommInitRank); RCCL_SYM(CommDestroy); RCCL_SYM(Send); RCCL_SYM(Recv); RCCL_SYM(Broadcast);
+        RCCL_SYM(AllReduce); RCCL_SYM(GroupStart); RCCL_SYM(GroupEnd); RCCL_SYM(GetErrorString);
+#undef RCCL_SYM
+        return true;
+    }
+};
+static RcclApi g_rccl;
+#define RCCLCHECK(expr)                                                                                     \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess) { fprintf(stderr, "aprilsam_amd: FATAL: %s failed: %s\n", #expr, g_rccl.GetErrorString(r_)); fflush(stderr); abort(); } \
+    } while (0)
+
+struct RcclTransport : Transport {
+    ncclComm_t comm = nullptr;
+    ~RcclTransport() override { if (comm) (void)g_rccl.CommDestroy(comm); }
+    void group_begin() override { RCCLCHECK(g_rccl.GroupStart()); }
+    void group_end() override { RCCLCHECK(g_rccl.GroupEnd()); }
+    void send(const double *dev, long long n, int dst, hipStream_t s) override { RCCLCHECK(g_rccl.Send(dev, (size_t)n, ncclFloat64, dst, comm, s)); }
+    void recv(double *dev, long long n, int src, hipStream_t s) override { RCCLCHECK(g_rccl.Recv(dev, (size_t)n, ncclFloat64, src, comm, s)); }
+    void bcast(double *dev, long long n, int root, hipStream_t s) override { RCCLCHECK(g_rccl.Broadcast(dev, dev, (size_t)n, ncclFloat64, root, comm, s)); }
+    void allreduce_sum(double *dev, long long n, hipStream_t s) override { RCCLCHECK(g_rccl.AllReduce(dev, dev, (size_t)n, ncclFloat64, ncclSum, comm, s)); }
+    const char *name() const override { return "rccl"; }
+};
+
+struct HostTransport : Transport {
+    aprilsam_amd_host_comm_t cb{};
+    HBuf<double> stage;
+    void down(const double *dev, long long n, hipStream_t s) { stage.need((size_t)n); HIPCHECK(hipMemcpyAsync(stage.p, dev, (size_t)n * 8, hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s)); }
+    void up(double *dev, long long n, hipStream_t s) { HIPCHECK(hipMemcpyAsync(dev, stage.p, (size_t)n * 8, hipMemcpyHostToDevice, s)); HIPCHECK(hipStreamSynchronize(s)); }
+    static void chk(int rc, const char *what) { if (rc != 0) { fprintf(stderr, "aprilsam_amd: FATAL: host communication callback %s returned %d\n", what, rc); fflush(stderr); abort(); } }
+    void send(const double *dev, long long n, int dst, hipStream_t s) override { down(dev, n, s); chk(cb.send(cb.user, stage.p, n, dst), "send"); }
+    void recv(double *dev, long long n, int src, hipStream_t s) override { stage.need((size_t)n); chk(cb.recv(cb.user, stage.p, n, src), "recv"); up(dev, n, s); }
+    void bcast(double *dev, long long n, int root, hipStream_t s) override { down(dev, n, s); chk(cb.bcast(cb.user, stage.p, n, root), "bcast"); up(dev, n, s); }
+    void allreduce_sum(double *dev, long long n, hipStream_t s) override { down(dev, n, s); chk(cb.allreduce_sum(cb.user, stage.p, n), "allreduce_sum"); up(dev, n, s); }
+    const char *name() const override { return "host callbacks"; }
+    ~HostTransport() override { stage.release(); }
+};
+
 struct ShardState {
     int rank = 0, world = 1;
     std::vector<int> owner;                  // per front
     std::vector<char> top;                   // per front: rank range spans more than one rank
+    ShardLayout lay;                         // this rank's front pool: owned fronts + ghosts of remote children
     std::vector<LevelPlan> levels;           // launch tables of the fronts THIS rank owns, per level
+    DBuf<int> d_tab;                         // ... their device copy
     DBuf<int> d_flist; int n_flist = 0;      // factors owned by this rank's fronts
+    DBuf<int> d_nown;                        // per node: rank that owns the front eliminating it
     std::vector<long long> xfer;             // transfers up: level, front, src, dst, offset (doubles), count (doubles)
     std::vector<long long> bcast;            // broadcasts down: level, front, owner, first position, own blocks
+    struct Xfer { int front, src, dst; long long count, boff; };
+    std::vector<std::vector<Xfer>> up;       // per level, global list order; boff = offset in d_send (src == rank) / d_recv (dst == rank)
+    std::vector<std::vector<std::array<long long, 3>>> down;   // per level: owner, 3 * first, 3 * nsb
+    DBuf<double> d_send, d_recv, d_scratch;
+    std::unique_ptr<Transport> tr;
+    void release() { d_tab.release(); d_flist.release(); d_nown.release(); d_send.release(); d_recv.release(); d_scratch.release(); tr.reset(); }
 };
 static std::unordered_map<const void *, std::unique_ptr<ShardState>> g_shard;
 
@@ -1506,6 +1786,9 @@ void shard_map(const Plan &P, int world, std::vector<int> &owner, std::vector<ch
     }
 }
 
+// Every rank calls this with the same graph.  Builds the (identical) plan, the ownership map, THIS rank's pool layout
+// (owned fronts + ghosts), launch tables and exchange buffers.  A transport must be attached before the first
+// iteration unless world == 1 (shard_comm_init_rccl / shard_comm_init_host).
 int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank, int world) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0 || world < 1 || rank < 0 || rank >= world) return -1;
     ensure_device();
@@ -1515,134 +1798,258 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
     pack_factors(gp, g);
     if (!gp.host_idx.empty()) return -4;
     pack_states(gp, g, false);
-    prepare_plan(c, gp, g);
-    upload_factors(gp);
-    set_lambda(c, gp, param->tikhanov);
+    c.have_plan = false;                      // the pool layout is per rank: never reuse an upload made for another layout
+    prepare_plan(c, gp, g, false);
     const Plan &P = c.plan;
+    { auto it = g_shard.find(param); if (it != g_shard.end()) { it->second->release(); g_shard.erase(it); } }
     auto &S = *(g_shard[param] = std::make_unique<ShardState>());
     S.rank = rank; S.world = world;
     shard_map(P, world, S.owner, S.top, S.xfer, S.bcast);
-    // launch tables of the owned fronts, appended behind the full tables
+    // ---- pool layout: owned fronts in plan order, then the ghosts of remote children -------------------------------
+    S.lay.off.assign(P.nF, -1); S.lay.ghost.assign(P.nF, 0);
+    long long run = 0;
+    for (int t = 0; t < P.nF; t++) if (S.owner[t] == rank) { run = (run + 31) & ~31ll; S.lay.off[t] = run; run += (long long)P.rows(t) * P.cols(t); }
+    for (int t = 0; t < P.nF; t++) {
+        const int par = P.f_parent[t];
+        if (par >= 0 && S.owner[par] == rank && S.owner[t] != rank) {
+            run = (run + 31) & ~31ll; S.lay.off[t] = run; S.lay.ghost[t] = 1;
+            run += (long long)(3 * P.f_nub[t] + 3) * (3 * P.f_nub[t]);
+        }
+    }
+    S.lay.pool_doubles = run;
+    upload_plan(c, gp.stream, &S.lay);
+    c.have_plan = false;                      // (a later non-sharded call on this param must re-upload the full layout)
+    upload_factors(gp);
+    set_lambda(c, gp, param->tikhanov);
+    // ---- launch tables of the owned fronts ------------------------------------------------------------------------
     std::vector<int> tab;
     S.levels.assign(P.nLevels, LevelPlan());
     for (int l = 0; l < P.nLevels; l++) {
         std::vector<int> fr;
         for (int k = P.lev_ptr[l]; k < P.lev_ptr[l + 1]; k++) if (S.owner[P.lev_fronts[k]] == rank) fr.push_back(P.lev_fronts[k]);
         build_level(S.levels[l], fr, tab, [&](int t, int *nsb, int *nub) { *nsb = P.f_nsb[t]; *nub = P.f_nub[t]; });
-        LevelPlan &L = S.levels[l];
-        const int sh = (int)c.inc.tab_used;
-        L.all_off += sh; L.small_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
-        for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
-        for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
-        for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
-        for (auto &x : L.syrka) { x.list_off += sh; x.pre_off += sh; }
-        for (auto &x : L.syrkb) { x.list_off += sh; x.pre_off += sh; }
-        L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh;
     }
-    if (c.inc.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return -3;
-    if (!tab.empty()) HIPCHECK(hipMemcpyAsync(c.d_tab.p + c.inc.tab_used, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, gp.stream));
-    // factors owned by this rank's fronts
+    if (tab.empty()) tab.push_back(0);
+    S.d_tab.need(tab.size());
+    HIPCHECK(hipMemcpyAsync(S.d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, gp.stream));
+    { int mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, S.levels[l].n_big); c.d_diag.need((size_t)(mx + 64) * NB * (NB + 1)); }
+    // ---- factors owned by this rank's fronts, node ownership ----------------------------------------------------
     std::vector<int> fl;
     for (int f = 0; f < P.F; f++) if (P.fac_front[f] >= 0 && S.owner[P.fac_front[f]] == rank) fl.push_back(f);
     S.n_flist = (int)fl.size();
     S.d_flist.need(std::max<size_t>(1, fl.size()));
     if (!fl.empty()) HIPCHECK(hipMemcpyAsync(S.d_flist.p, fl.data(), fl.size() * 4, hipMemcpyHostToDevice, gp.stream));
+    std::vector<int> nown(P.N, 0);
+    for (int t = 0; t < P.nF; t++) for (int k = 0; k < P.f_nsb[t]; k++) nown[P.perm[P.f_first[t] + k]] = S.owner[t];
+    S.d_nown.need(P.N);
+    HIPCHECK(hipMemcpyAsync(S.d_nown.p, nown.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, gp.stream));
+    // ---- exchange lists of this rank ------------------------------------------------------------------------------
+    S.up.assign(P.nLevels, {}); S.down.assign(P.nLevels, {});
+    long long send_max = 1, recv_max = 1;
+    for (size_t i = 0; i + 5 < S.xfer.size() + 1 && i < S.xfer.size(); i += 6) {
+        const int lev = (int)S.xfer[i], front = (int)S.xfer[i + 1], src = (int)S.xfer[i + 2], dst = (int)S.xfer[i + 3];
+        S.up[lev].push_back({ front, src, dst, S.xfer[i + 5], 0 });
+    }
+    for (int l = 0; l < P.nLevels; l++) {
+        long long so = 0, ro = 0;
+        for (auto &x : S.up[l]) {
+            if (x.src == rank) { x.boff = so; so += x.count; }
+            else if (x.dst == rank) { x.boff = ro; ro += x.count; }
+        }
+        send_max = std::max(send_max, so); recv_max = std::max(recv_max, ro);
+    }
+    for (size_t i = 0; i < S.bcast.size(); i += 5) S.down[(int)S.bcast[i]].push_back({ S.bcast[i + 2], 3 * S.bcast[i + 3], 3 * S.bcast[i + 4] });
+    S.d_send.need((size_t)send_max); S.d_recv.need((size_t)recv_max);
     HIPCHECK(hipMemsetAsync(c.d_x.p, 0, (size_t)24 * gp.N, gp.stream));     // poses of other ranks' subtrees simply do not move here
-    HIPCHECK(hipStreamSynchronize(gp.stream));
+    HIPCHECK(hipStreamSynchronize(gp.stream));      // host vectors above go out of scope
     c.st.n_nodes = gp.N; c.st.n_factors = gp.F;
     return 0;
 }
-// what: 0 -> #levels, 1 -> xfer (6 per entry), 2 -> bcast (5 per entry), 3 -> owner per front.  Returns count written (or needed if out == null)
+// what: 0 -> {levels, fronts, nodes, pool doubles of this rank, pool doubles of the whole plan}, 1 -> xfer (6 per entry),
+// 2 -> bcast (5 per entry), 3 -> owner per front.  Returns count written (or needed if out == null)
 long long shard_info(const april_graph_cholesky_param_t *param, int what, long long *out, long long cap) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_shard.find(param); auto ic = g_ctx.find(param);
     if (it == g_shard.end() || ic == g_ctx.end()) return -1;
     const ShardState &S = *it->second;
     std::vector<long long> v;
-    if (what == 0) v = { ic->second->plan.nLevels, ic->second->plan.nF, ic->second->plan.N };
+    if (what == 0) v = { ic->second->plan.nLevels, ic->second->plan.nF, ic->second->plan.N, S.lay.pool_doubles, (long long)ic->second->plan.pool_doubles };
     else if (what == 1) v = S.xfer;
     else if (what == 2) v = S.bcast;
     else if (what == 3) v.assign(S.owner.begin(), S.owner.end());
     if (out) for (long long i = 0; i < (long long)v.size() && i < cap; i++) out[i] = v[i];
     return (long long)v.size();
 }
-// op: 0 relinearise + linearise owned factors; 1 factor level `arg`; 2 back-substitute level `arg`; 3 state update; 4 stream sync
-int shard_step(april_graph_t *g, april_graph_cholesky_param_t *param, int op, int arg) {
+
+// ---- attaching a transport --------------------------------------------------------------------------------------
+int shard_comm_unique_id(char *out128) {
+    ensure_device();
+    if (!g_rccl.load()) return -5;
+    ncclUniqueId id;
+    const ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) { fprintf(stderr, "aprilsam_amd: ncclGetUniqueId failed: %s\n", g_rccl.GetErrorString(r)); return -6; }
+    memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+int shard_comm_init_rccl(const april_graph_cholesky_param_t *param, const char *id128) {
+    ensure_device();
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_shard.find(param);
+    if (it == g_shard.end()) return -1;
+    if (!g_rccl.load()) return -5;
+    ShardState &S = *it->second;
+    auto T = std::make_unique<RcclTransport>();
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    HIPCHECK(hipSetDevice(g_device));
+    const ncclResult_t r = g_rccl.CommInitRank(&T->comm, S.world, id, S.rank);
+    if (r != ncclSuccess) { fprintf(stderr, "aprilsam_amd: ncclCommInitRank failed: %s\n", g_rccl.GetErrorString(r)); return -6; }
+    S.tr = std::move(T);
+    return 0;
+}
+int shard_comm_init_host(const april_graph_cholesky_param_t *param, const aprilsam_amd_host_comm_t *cb) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_shard.find(param);
+    if (it == g_shard.end() || !cb || !cb->send || !cb->recv || !cb->bcast || !cb->allreduce_sum) return -1;
+    auto T = std::make_unique<HostTransport>();
+    T->cb = *cb;
+    it->second->tr = std::move(T);
+    return 0;
+}
+
+// n Gauss-Newton iterations of the sharded solve: per level the owned fronts, then the Schur slabs whose parent lives on
+// another rank (packed lower trapezoid, point to point); on the way down the solved x of the top fronts (broadcast).
+int shard_iterate(april_graph_t *g, april_graph_cholesky_param_t *param, int n) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_shard.find(param); auto ic = g_ctx.find(param);
     if (it == g_shard.end() || ic == g_ctx.end()) return -1;
     ShardState &S = *it->second; Context &c = *ic->second;
+    if (S.world > 1 && !S.tr) return -7;
     GraphPack &gp = pack_for(g);
+    const Plan &P = c.plan;
     hipStream_t s = gp.stream;
     HIPCHECK(hipSetDevice(g_device));
     set_small_attr();
-    const int N = gp.N;
+    const int N = gp.N, me = S.rank;
     auto nop = [](int) {}; auto nop0 = []() {};
-    if (op == 0) {
-        HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
+    Transport *T = S.tr.get();
+    for (int iter = 0; iter < n; iter++) {
+        HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));      // relinearise
         HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 16, s));
         if (S.n_flist)
             hipLaunchKernelGGL(k_linearize, dim3((S.n_flist + TPB - 1) / TPB), dim3(TPB), 0, s, 0, S.n_flist, (const int *)S.d_flist.p, gp.d_fa.p, gp.d_fb.p,
-                               gp.d_z.p, gp.d_W.p, gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
-    } else if (op == 1) {
-        c.la_next = 0;
-        enqueue_factor_level(c, S.levels[arg], s, nop, nop0, g_opt.lookahead != 0);
-    } else if (op == 2) {
-        const LevelPlan &L = S.levels[arg];
-        launch_backsolve(c, L, s, nop, nop0);
-    } else if (op == 3) {
-        hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
-    } else if (op == 4) {
-        HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, s));
-        HIPCHECK(hipStreamSynchronize(s));
-        return c.h_bad.p[0] ? -2 : 0;
+                               gp.d_z.p, gp.d_W.p, gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, (int *)nullptr, (const double *)nullptr);
+        for (int l = 0; l < P.nLevels; l++) {
+            c.la_next = 0;
+            enqueue_factor_level(c, S.levels[l], s, nop, nop0, g_opt.lookahead != 0, S.d_tab.p);
+            if (S.up[l].empty() || !T) continue;
+            bool any = false;
+            for (const auto &x : S.up[l]) {
+                if (x.src != me) continue;
+                const int R = P.rows(x.front), C = P.cols(x.front), ns = 3 * P.f_nsb[x.front];
+                if (C > ns) hipLaunchKernelGGL(k_pack_update, dim3(C - ns), dim3(TPB), 0, s, c.d_pool.p + S.lay.off[x.front], R, ns, S.d_send.p + x.boff, 0);
+                any = true;
+            }
+            for (const auto &x : S.up[l]) any = any || x.dst == me;
+            if (!any) continue;
+            T->group_begin();
+            for (const auto &x : S.up[l]) {
+                if (x.src == me) T->send(S.d_send.p + x.boff, x.count, x.dst, s);
+                else if (x.dst == me) T->recv(S.d_recv.p + x.boff, x.count, x.src, s);
+            }
+            T->group_end();
+            for (const auto &x : S.up[l]) {
+                if (x.dst != me) continue;
+                const int cnu = P.f_nub[x.front];       // ghost = the update block alone: a front with no own columns
+                if (cnu > 0) hipLaunchKernelGGL(k_pack_update, dim3(3 * cnu), dim3(TPB), 0, s, c.d_pool.p + S.lay.off[x.front], 3 * cnu + 3, 0, S.d_recv.p + x.boff, 1);
+            }
+        }
+        for (int l = P.nLevels - 1; l >= 0; l--) {
+            launch_backsolve(c, S.levels[l], s, nop, nop0, S.d_tab.p);
+            if (S.down[l].empty() || !T) continue;
+            T->group_begin();
+            for (const auto &b : S.down[l]) T->bcast(c.d_x.p + b[1], b[2], (int)b[0], s);
+            T->group_end();
+        }
+        hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
+                           (double *)nullptr, (double *)nullptr, (const int *)nullptr, (int *)nullptr);
+        HIPCHECK(hipGetLastError());
     }
-    HIPCHECK(hipGetLastError());
-    return 0;
+    HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    c.st.not_spd = c.h_bad.p[0] != 0;
+    return c.h_bad.p[0] ? -2 : 0;
 }
-// copy `count` doubles between the front pool (kind 0, offset in doubles) or the solution vector x (kind 1, offset in
-// doubles by elimination position*3) and a caller buffer (device or host pointer); dir 0: library -> buffer, 1: buffer -> library
-int shard_copy(april_graph_t *g, april_graph_cholesky_param_t *param, int kind, long long offset, long long count, void *buf, int dir) {
+
+// After the iterations every rank holds the states of its own subtrees and of the top fronts.  Gather: states, l_points
+// and dx masked by node ownership, summed over the ranks (x + 0 + ... + 0 is exact: every rank ends up with bit-identical
+// copies), written into the device arrays and into the caller's node objects like a resident run does.
+int shard_gather_states(april_graph_t *g, april_graph_cholesky_param_t *param) {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto ic = g_ctx.find(param);
-    if (ic == g_ctx.end()) return -1;
-    Context &c = *ic->second;
+    auto it = g_shard.find(param); auto ic = g_ctx.find(param);
+    if (it == g_shard.end() || ic == g_ctx.end()) return -1;
+    ShardState &S = *it->second; Context &c = *ic->second;
+    if (S.world > 1 && !S.tr) return -7;
     GraphPack &gp = pack_for(g);
-    if (kind == 2) {         // packed Schur update of front `offset`; buf must be a device pointer
-        const Plan &P = c.plan;
-        const int t = (int)offset;
-        if (t < 0 || t >= P.nF) return -1;
-        const int R = P.rows(t), C = P.cols(t), ns = 3 * P.f_nsb[t];
-        if (count != upd_packed_offset(R, ns, C)) return -2;
-        if (C > ns) hipLaunchKernelGGL(k_pack_update, dim3(C - ns), dim3(TPB), 0, gp.stream, c.d_pool.p + P.f_off[t], R, ns, (double *)buf, dir);
-        HIPCHECK(hipStreamSynchronize(gp.stream));
-        return 0;
+    hipStream_t s = gp.stream;
+    HIPCHECK(hipSetDevice(g_device));
+    const int N = gp.N;
+    if (S.tr) {
+        S.d_scratch.need((size_t)9 * N);
+        hipLaunchKernelGGL(k_mask_owned, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, S.d_nown.p, S.rank, gp.d_state.p, gp.d_lp.p, gp.d_dx.p, S.d_scratch.p);
+        S.tr->allreduce_sum(S.d_scratch.p, (long long)9 * N, s);
+        HIPCHECK(hipMemcpyAsync(gp.d_state.p, S.d_scratch.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(gp.d_lp.p, S.d_scratch.p + (size_t)3 * N, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(gp.d_dx.p, S.d_scratch.p + (size_t)6 * N, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
     }
-    double *p = (kind == 0 ? c.d_pool.p : c.d_x.p) + offset;
-    HIPCHECK(hipMemcpyAsync(dir == 0 ? buf : (void *)p, dir == 0 ? (void *)p : buf, (size_t)count * 8, hipMemcpyDefault, gp.stream));
-    HIPCHECK(hipStreamSynchronize(gp.stream));
+    HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(gp.h_lp.p, gp.d_lp.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
+    for (int i = 0; i < N; i++) {
+        april_graph_node_t *nd = ns[i];
+        nd->UID = i;
+        memcpy(nd->state, gp.h_state.p + (size_t)3 * i, 24);
+        memcpy(nd->l_point, gp.h_lp.p + (size_t)3 * i, 24);
+        const double *dx = gp.h_dx.p + (size_t)3 * i;
+        if (!(std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2]))) memcpy(nd->delta_X, dx, 24);
+    }
+    if (param->ordering) free(param->ordering);
+    param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
+    memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
+    param->nreordering = N; param->factor_num = gp.F;
     return 0;
 }
-// chi^2 of the factors owned by this rank, at the resident states (sum over ranks = april_graph_chi2)
-double shard_chi2_local(april_graph_t *g, april_graph_cholesky_param_t *param) {
+// chi^2 at the resident states: every rank sums the factors its fronts own, the transport adds the partial sums
+double shard_chi2(april_graph_t *g, april_graph_cholesky_param_t *param) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_shard.find(param); auto ic = g_ctx.find(param);
     if (it == g_shard.end() || ic == g_ctx.end()) return -1;
     GraphPack &gp = pack_for(g);
-    const Plan &P = ic->second->plan; const ShardState &S = *it->second;
+    const Plan &P = ic->second->plan; ShardState &S = *it->second;
     hipStream_t s = gp.stream;
+    HIPCHECK(hipSetDevice(g_device));
     hipLaunchKernelGGL(k_chi2, dim3((gp.F + TPB - 1) / TPB), dim3(TPB), 0, s, gp.F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p, gp.d_state.p, gp.d_chi2f.p);
     std::vector<double> h(gp.F);
     HIPCHECK(hipMemcpyAsync(h.data(), gp.d_chi2f.p, (size_t)8 * gp.F, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     double acc = 0;
     for (int f = 0; f < gp.F; f++) if (P.fac_front[f] >= 0 && S.owner[P.fac_front[f]] == S.rank) acc += h[f];
+    if (S.tr) {
+        HIPCHECK(hipMemcpyAsync(gp.d_scalar.p, &acc, 8, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        S.tr->allreduce_sum(gp.d_scalar.p, 1, s);
+        HIPCHECK(hipMemcpyAsync(gp.h_scalar.p, gp.d_scalar.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        acc = gp.h_scalar.p[0];
+    }
     return acc;
 }
 void shard_end(const april_graph_cholesky_param_t *param) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_shard.find(param);
-    if (it != g_shard.end()) { it->second->d_flist.release(); g_shard.erase(it); }
+    if (it != g_shard.end()) { it->second->release(); g_shard.erase(it); }
 }
 
 // ------------------------------------------------------------------------------------------------------

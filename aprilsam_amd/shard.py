@@ -1,18 +1,26 @@
-"""Host driver of the multi-GPU path: one process per GPU, torch.distributed for the exchange (backend "nccl" =
-RCCL over xGMI on the 8-GPU node; "gloo" with host staging in the tests, where the ranks share one GPU).
+"""Launcher of the multi-GPU path: one process per GPU.  The library owns everything that matters -- plan, ownership
+map, per-rank front pool, kernels AND the exchange (include/aprilsam_amd.h, aprilsam_amd_shard_*): with backend "nccl"
+it talks RCCL over xGMI itself, on its own HIP stream (ncclSend / ncclRecv of the packed Schur slabs, ncclBroadcast of
+the separator solutions); this module only hands it the RCCL unique id.  With backend "gloo" (the tests: several ranks
+sharing one GPU, which RCCL cannot do) the library stages every buffer through pinned host memory and calls back into
+the four functions below, which move it with torch.distributed.
 
-The library (include/aprilsam_amd.h, aprilsam_amd_shard_*) owns the plan, the ownership map and every kernel;
-this module only sequences the per-level steps and moves the two kinds of data that cross ranks:
-
-  up   — the Schur update of a front whose parent lives on another rank, packed to the lower trapezoid the
-         parent's assembly reads (k_pack_update): send/recv, point to point
-  down — the solved x of the top fronts (a few thousand doubles each): broadcast
-
-There is no all-reduce on the data path; chi^2 (outside the timed region) is one scalar all-reduce.
+There is no all-reduce on the data path; chi^2 and the final gather of the states (outside the timed region) are sums
+over the ranks.
 """
 import ctypes as C
 
 import numpy as np
+
+_SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_longlong, C.c_int)
+_RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_longlong, C.c_int)
+_BCAST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_longlong, C.c_int)
+_ALLRED = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_longlong)
+
+
+class HostComm(C.Structure):
+    """aprilsam_amd_host_comm_t"""
+    _fields_ = [("user", C.c_void_p), ("send", _SEND), ("recv", _RECV), ("bcast", _BCAST), ("allreduce_sum", _ALLRED)]
 
 
 class ShardedSolver:
@@ -21,32 +29,75 @@ class ShardedSolver:
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.lib, self.g, self.p, self.rank, self.world = lib, graph, param, rank, world
-        self.on_gpu = backend == "nccl"
-        self.dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if self.on_gpu else torch.device("cpu"))
+        self.backend = backend
         d = lib.dll
         d.aprilsam_amd_shard_info.restype = C.c_longlong
         d.aprilsam_amd_shard_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.c_longlong]
-        d.aprilsam_amd_shard_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong, C.c_void_p, C.c_int]
-        d.aprilsam_amd_shard_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         d.aprilsam_amd_shard_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
-        d.aprilsam_amd_shard_chi2_local.restype = C.c_double
-        d.aprilsam_amd_shard_chi2_local.argtypes = [C.c_void_p, C.c_void_p]
+        d.aprilsam_amd_shard_iterate.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        d.aprilsam_amd_shard_gather_states.argtypes = [C.c_void_p, C.c_void_p]
+        d.aprilsam_amd_shard_chi2.restype = C.c_double
+        d.aprilsam_amd_shard_chi2.argtypes = [C.c_void_p, C.c_void_p]
+        d.aprilsam_amd_shard_comm_unique_id.argtypes = [C.c_char_p]
+        d.aprilsam_amd_shard_comm_init_rccl.argtypes = [C.c_void_p, C.c_char_p]
+        d.aprilsam_amd_shard_comm_init_host.argtypes = [C.c_void_p, C.POINTER(HostComm)]
         d.aprilsam_amd_shard_end.argtypes = [C.c_void_p]
         self._g = C.cast(graph.ptr, C.c_void_p); self._p = C.cast(param.ptr, C.c_void_p)
         rc = d.aprilsam_amd_shard_begin(self._g, self._p, rank, world)
         if rc != 0:
             raise RuntimeError(f"shard_begin failed rc={rc}")
-        self.n_levels, self.n_fronts, self.n_nodes = self._info(0)
-        self.xfer = self._info(1).reshape(-1, 6)       # level, front, src, dst, pool offset, count
+        self.n_levels, self.n_fronts, self.n_nodes, self.pool_doubles, self.pool_doubles_all = (int(v) for v in self._info(0))
+        self.xfer = self._info(1).reshape(-1, 6)       # level, front, src, dst, -, packed count
         self.bcast = self._info(2).reshape(-1, 5)      # level, front, owner, first position, blocks
         self.owner = self._info(3)
-        self.up = [self.xfer[self.xfer[:, 0] == l] for l in range(self.n_levels)]
-        self.down = [self.bcast[self.bcast[:, 0] == l] for l in range(self.n_levels)]
-        nmax = int(max([1] + [int(r[5]) for r in self.xfer] + [3 * int(r[4]) for r in self.bcast]))
-        # dbuf: device buffer the library packs into / unpacks from; buf: what torch.distributed moves (the same
-        # tensor with RCCL, a host mirror with gloo)
-        self.dbuf = torch.empty(nmax, dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
-        self.buf = self.dbuf if self.on_gpu else torch.empty(nmax, dtype=torch.float64, device="cpu")
+        if world > 1 or backend == "nccl":
+            if backend == "nccl":
+                self._init_rccl(device)
+            else:
+                self._init_host()
+
+    # -- transports ---------------------------------------------------------------------------------------------------
+    def _init_rccl(self, device):
+        """rank 0 asks the library for an RCCL unique id; torch.distributed only carries these 128 bytes"""
+        torch, dist = self.torch, self.dist
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            rc = self.lib.dll.aprilsam_amd_shard_comm_unique_id(buf)
+            if rc != 0:
+                raise RuntimeError(f"shard_comm_unique_id rc={rc}")
+        if self.world > 1:
+            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+            t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(t, src=0)
+            buf = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        rc = self.lib.dll.aprilsam_amd_shard_comm_init_rccl(self._p, buf)
+        if rc != 0:
+            raise RuntimeError(f"shard_comm_init_rccl rc={rc}")
+
+    def _init_host(self):
+        torch, dist = self.torch, self.dist
+
+        def view(ptr, n):
+            return torch.from_numpy(np.ctypeslib.as_array(ptr, shape=(int(n),)))
+
+        def guard(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as e:        # never let an exception cross the C boundary
+                    print("aprilsam_amd.shard: communication callback failed:", repr(e), flush=True)
+                    return 1
+            return run
+
+        self._cb = HostComm(None,
+                            _SEND(guard(lambda u, p, n, dst: dist.send(view(p, n), dst=int(dst)))),
+                            _RECV(guard(lambda u, p, n, src: dist.recv(view(p, n), src=int(src)))),
+                            _BCAST(guard(lambda u, p, n, root: dist.broadcast(view(p, n), src=int(root)))),
+                            _ALLRED(guard(lambda u, p, n: dist.all_reduce(view(p, n)))))
+        rc = self.lib.dll.aprilsam_amd_shard_comm_init_host(self._p, C.byref(self._cb))
+        if rc != 0:
+            raise RuntimeError(f"shard_comm_init_host rc={rc}")
 
     def _info(self, what):
         n = self.lib.dll.aprilsam_amd_shard_info(self._p, what, None, 0)
@@ -54,60 +105,23 @@ class ShardedSolver:
         self.lib.dll.aprilsam_amd_shard_info(self._p, what, out.ctypes.data_as(C.POINTER(C.c_longlong)), n)
         return out[:n]
 
-    def _step(self, op, arg=0):
-        rc = self.lib.dll.aprilsam_amd_shard_step(self._g, self._p, op, arg)
-        if rc != 0:
-            raise RuntimeError(f"shard_step({op},{arg}) rc={rc}")
-
-    def _copy(self, kind, off, cnt, to_lib):
-        """kind 2: packed Schur update of front `off`; kind 1: x at elimination offset `off`.  Synchronous."""
-        cnt = int(cnt)
-        if to_lib and not self.on_gpu:
-            self.dbuf[:cnt].copy_(self.buf[:cnt]); self.torch.cuda.synchronize()
-        rc = self.lib.dll.aprilsam_amd_shard_copy(self._g, self._p, kind, int(off), cnt, C.c_void_p(self.dbuf.data_ptr()), 1 if to_lib else 0)
-        if rc != 0:
-            raise RuntimeError(f"shard_copy(kind={kind}) rc={rc}")
-        if not to_lib and not self.on_gpu:
-            self.buf[:cnt].copy_(self.dbuf[:cnt])
-
-    def _comm_done(self):
-        """With RCCL a collective / send / recv returns once it is ENQUEUED (the wait only chains the current torch stream
-        behind the communication stream).  The library packs and unpacks on its own HIP stream, which torch knows nothing
-        about, so the host has to wait for the communication before the buffer is read or overwritten."""
-        if self.on_gpu:
-            self.torch.cuda.current_stream().synchronize()
-
+    # -- the solve ----------------------------------------------------------------------------------------------------
     def iterate(self, n=1):
-        dist = self.dist
-        for _ in range(n):
-            self._step(0)
-            for l in range(self.n_levels):
-                self._step(1, l)
-                for _, front, src, dst, off, cnt in self.up[l]:
-                    if self.rank == src:
-                        self._copy(2, front, cnt, False)
-                        dist.send(self.buf[:cnt], dst=int(dst)); self._comm_done()
-                    elif self.rank == dst:
-                        dist.recv(self.buf[:cnt], src=int(src)); self._comm_done()
-                        self._copy(2, front, cnt, True)
-            for l in range(self.n_levels - 1, -1, -1):
-                self._step(2, l)
-                for _, front, owner, first, nsb in self.down[l]:
-                    cnt = 3 * int(nsb)
-                    if self.rank == owner:
-                        self._copy(1, 3 * int(first), cnt, False)
-                    dist.broadcast(self.buf[:cnt], src=int(owner)); self._comm_done()
-                    if self.rank != owner:
-                        self._copy(1, 3 * int(first), cnt, True)
-            self._step(3)
-        rc = self.lib.dll.aprilsam_amd_shard_step(self._g, self._p, 4, 0)
-        if rc != 0:
+        rc = self.lib.dll.aprilsam_amd_shard_iterate(self._g, self._p, int(n))
+        if rc == -2:
             raise ArithmeticError("sharded solve: not positive definite")
+        if rc != 0:
+            raise RuntimeError(f"shard_iterate rc={rc}")
 
     def chi2(self):
-        t = self.torch.tensor([self.lib.dll.aprilsam_amd_shard_chi2_local(self._g, self._p)], dtype=self.torch.float64, device=self.dev)
-        self.dist.all_reduce(t)
-        return float(t.item())          # .item() synchronises
+        return float(self.lib.dll.aprilsam_amd_shard_chi2(self._g, self._p))
+
+    def gather_states(self):
+        """every rank ends up with all states (device arrays and node objects); returns them as an (N, 3) array"""
+        rc = self.lib.dll.aprilsam_amd_shard_gather_states(self._g, self._p)
+        if rc != 0:
+            raise RuntimeError(f"shard_gather_states rc={rc}")
+        return self.g.states()
 
     def comm_bytes_per_iteration(self):
         return int(8 * (self.xfer[:, 5].sum() + 3 * self.bcast[:, 4].sum() * (self.world - 1)))

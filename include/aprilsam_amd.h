@@ -223,7 +223,10 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *   "deterministic"     1 = disable the wall-clock fallback rule aprilsam.c:557 (default 1)
  *   "use_graph"         1 = replay the numeric phase from a captured hipGraph (default 1)
  *   "device_timing"     1 = record per-stage HIP events (default 0)
- *   "trust_factor_cache" 1 = z/W of already-seen factors are immutable (default 1)
+ *   "trust_factor_cache" 1 = z/W of already-packed factors are treated as immutable: skips the per-call re-read and
+ *                       comparison of every factor object (default 0: reference semantics, edits in place are seen)
+ *   "block_factor"      0 = per-3x3-pivot elimination through LDS in the single-workgroup front kernel (default 1: 16 columns
+ *                       at a time in registers)
  *   "small_lds_kb"      LDS budget (KiB) of the single-workgroup front kernel: fronts whose whole array fits run fully
  *                       in LDS, fronts whose own columns fit run in panel mode, the rest takes the multi-workgroup
  *                       path (default 156; 0 forces the multi-workgroup path everywhere)
@@ -263,25 +266,49 @@ int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, doubl
                                 double *flops, double *bytes, const char **names);
 
 /* ---- multi-GPU: nested-dissection subtree sharding, one process per GPU -------
- * Every rank calls shard_begin with the same graph: identical plans, fronts split over ranks by proportional
- * mapping of the assembly tree.  One Gauss-Newton iteration = shard_step(op 0) ; for each level l ascending
- * { shard_step(1, l) ; transfers "up" of level l } ; for each level l descending { shard_step(2, l) ;
- * broadcasts "down" of level l } ; shard_step(3).  The exchanges (RCCL send/recv of one packed Schur update per
- * transfer, broadcast of a few thousand doubles per top front) are issued by the host driver — see
- * aprilsam_amd/shard.py — between library calls; shard_copy moves the slabs between the library's HBM and the
- * driver's communication buffers.
- *   shard_info what: 0 -> {levels, fronts, nodes}; 1 -> transfers {level, front, src, dst, pool offset, packed count} (doubles);
+ * The reference has no counterpart (it is sequential); a C host drives a sharded solve through the same graph / param
+ * objects it hands to april_graph_cholesky (aprilsam.h:268-281):
+ *
+ *     aprilsam_amd_shard_begin(graph, param, rank, world);            every rank, same graph: identical plans, fronts split
+ *                                                                     over the ranks by proportional mapping of the assembly
+ *                                                                     tree; THIS rank allocates only the fronts it owns plus
+ *                                                                     "ghost" update blocks of children that live elsewhere
+ *     aprilsam_amd_shard_comm_unique_id(id)  on rank 0, id sent to the other ranks by any means (file, socket, MPI, ...)
+ *     aprilsam_amd_shard_comm_init_rccl(param, id);                   RCCL communicator over xGMI on the library's device
+ *       -- or aprilsam_amd_shard_comm_init_host(param, &callbacks);   the caller moves pinned host buffers itself
+ *     aprilsam_amd_shard_iterate(graph, param, n);                    n Gauss-Newton iterations; the exchange happens inside:
+ *                                                                     per level, the Schur update of every front whose parent
+ *                                                                     lives on another rank (packed lower trapezoid, point to
+ *                                                                     point); on the way down the solved x of the "top"
+ *                                                                     fronts (broadcast).  With RCCL everything is enqueued
+ *                                                                     on the solver's HIP stream: no host synchronisation
+ *                                                                     between a level's kernels and its transfers.
+ *     aprilsam_amd_shard_chi2(graph, param);                          chi^2 of the whole graph (partial sums added)
+ *     aprilsam_amd_shard_gather_states(graph, param);                 every rank ends up with ALL states / l_points / dx,
+ *                                                                     in HBM and in the node objects
+ *     aprilsam_amd_shard_end(param);
+ *
+ * No all-reduce on the data path; world = 1 needs no transport.
+ *   shard_info what: 0 -> {levels, fronts, nodes, pool doubles of this rank, pool doubles of the whole plan};
+ *                    1 -> transfers {level, front, src, dst, (unused), packed count in doubles};
  *                    2 -> broadcasts {level, front, owner, first position, blocks}; 3 -> owner rank per front
- *   shard_step op  : 0 relinearise + linearise owned factors, 1 factor level arg, 2 back-substitute level arg,
- *                    3 state update, 4 synchronise (returns -2 on a non-positive pivot)
- *   shard_copy kind: 0 front pool, 1 solution vector x (offsets/counts in doubles), 2 packed Schur update of front
- *                    `offset` (lower trapezoid of its update columns incl. the rhs row; buf must be DEVICE memory and
- *                    count the packed count of shard_info); dir 0 library -> buf, 1 buf -> library */
+ * Return codes: 0 ok; -1 bad arguments / no shard_begin; -2 non-positive pivot; -4 foreign factor types; -5 librccl.so not
+ * loadable; -6 RCCL error; -7 no transport attached. */
+typedef struct aprilsam_amd_host_comm {
+    void *user;                                                           /* passed back to every callback */
+    int (*send)(void *user, const double *buf, long long count, int dst);           /* blocking; 0 = ok */
+    int (*recv)(void *user, double *buf, long long count, int src);
+    int (*bcast)(void *user, double *buf, long long count, int root);               /* in place */
+    int (*allreduce_sum)(void *user, double *buf, long long count);                 /* in place */
+} aprilsam_amd_host_comm_t;
 int       aprilsam_amd_shard_begin(april_graph_t *graph, april_graph_cholesky_param_t *param, int rank, int world);
 long long aprilsam_amd_shard_info(const april_graph_cholesky_param_t *param, int what, long long *out, long long cap);
-int       aprilsam_amd_shard_step(april_graph_t *graph, april_graph_cholesky_param_t *param, int op, int arg);
-int       aprilsam_amd_shard_copy(april_graph_t *graph, april_graph_cholesky_param_t *param, int kind, long long offset, long long count, void *buf, int dir);
-double    aprilsam_amd_shard_chi2_local(april_graph_t *graph, april_graph_cholesky_param_t *param);
+int       aprilsam_amd_shard_comm_unique_id(char *out128);
+int       aprilsam_amd_shard_comm_init_rccl(april_graph_cholesky_param_t *param, const char *id128);
+int       aprilsam_amd_shard_comm_init_host(april_graph_cholesky_param_t *param, const aprilsam_amd_host_comm_t *callbacks);
+int       aprilsam_amd_shard_iterate(april_graph_t *graph, april_graph_cholesky_param_t *param, int n);
+int       aprilsam_amd_shard_gather_states(april_graph_t *graph, april_graph_cholesky_param_t *param);
+double    aprilsam_amd_shard_chi2(april_graph_t *graph, april_graph_cholesky_param_t *param);
 void      aprilsam_amd_shard_end(april_graph_cholesky_param_t *param);
 
 /* ---- host-logic introspection (no GPU needed): ordering + symbolic analysis of a graph -------- */
@@ -322,6 +349,15 @@ int aprilsam_amd_lattice_arrays(int K, double *states, int *fa, int *fb, double 
 /* Bulk append N xyt nodes (state = init = truth) and F factors (fb[i] < 0: xytpos prior on fa[i]). */
 void aprilsam_amd_graph_from_arrays(april_graph_t *graph, int N, const double *states, int F, const int *fa,
                                     const int *fb, const double *z, const double *W);
+
+/* Stage-level parity exports (tests/test_gpu_stages.py): the device linearisation and the gather assembly seen in the
+ * caller's node coordinates, at the graph's current states (l_point <- state first, as a batch step does).
+ *   what 0: out[33 * F], per factor (J_a^T W) J_a, (J_a^T W) J_b, (J_b^T W) J_b (3 x 3 row-major each), (J_a^T W) r, (J_b^T W) r
+ *           -- the products the reference forms at aprilsam.c:159-192 from april_graph_xyt.c:62-124 / april_graph_xytpos.c:63-102
+ *   what 1: out[9 N^2 + 3 N]: A = sum J^T W J + tikhanov * I (dense, symmetric, row-major) then B = sum J^T W r, both in
+ *           node order -- param->A (un-permuted) and param->B of aprilsam.c:159-204; N <= 2000
+ * Returns 0, or < 0 (empty graph, foreign factor types, too large). */
+int aprilsam_amd_debug_stage(april_graph_t *graph, april_graph_cholesky_param_t *param, int what, double *out);
 
 /* debug (env APRILSAM_AMD_KPROF=1): 16 wall-clock stamps (100 MHz ticks) per front from the last numeric pass */
 int aprilsam_amd_debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts);

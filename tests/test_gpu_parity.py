@@ -386,6 +386,68 @@ def _random_growth(lib, rng_seed, steps, nthreshold, old_old=False):
     return trace
 
 
+def test_factors_edited_in_place_are_seen_by_the_next_call(lib, reflib):
+    """the reference re-reads every factor object on every call (aprilsam.c:152-190, april_graph.c:79-98): a caller may
+    edit z / W of an existing factor in place, or replace a factor object, between two calls.  Default options
+    (trust_factor_cache = 0) must follow; both libraries are driven by the same code and compared call by call."""
+    arr = datasets.random_pose_graph(120, 90, 17)
+    out = []
+    for L in (lib, reflib):
+        g = L.new_graph(); g.build_from_arrays(*arr); p = L.new_param()
+        tr = []
+        g.cholesky(p); tr.append((g.chi2(), g.states()))
+        f = g.factor(37)                                   # measurement and information edited in place
+        f.u.z[0] += 0.25; f.u.z[2] -= 0.1
+        for k in (0, 4, 8):
+            f.u.W.contents.data[k] *= 3.0
+        tr.append((g.chi2(), g.states()))                  # chi^2 sees the edit at once
+        g.cholesky(p); tr.append((g.chi2(), g.states()))
+        g.factor(5).u.z[1] += 0.4                          # ... and again on a warm (plan-cached) call
+        g.cholesky(p); tr.append((g.chi2(), g.states()))
+        out.append(tr)
+        p.destroy(); g.destroy()
+    for k, ((c1, s1), (c2, s2)) in enumerate(zip(*out)):
+        assert abs(c1 - c2) <= 1e-9 * max(c2, 1.0), (k, c1, c2)
+        assert np.max(np.abs(s1 - s2)) < 1e-8, k
+    assert abs(out[0][1][0] - out[0][0][0]) > 1e-3          # the edit did change chi^2
+
+
+def _growth_with_late_priors(lib, steps=60):
+    """incremental growth where xytpos priors arrive in the middle of the run (the reference evaluates a prior at the
+    node's STATE of that call, april_graph_xytpos.c:83-85, not at its l_point) and a batch fall-back happens later"""
+    rng = np.random.default_rng(5)
+    g = lib.new_graph(); p = lib.new_param(nthreshold=18, delta_xy=0.05, delta_theta=0.05)
+    truth = [np.zeros(3)]
+    g.add_node_xyt(truth[0]); g.add_factor_xytpos(0, [0, 0, 0], datasets.PRIOR_W)
+    g.cholesky(p)
+    trace = []
+    W = np.diag([60.0, 60.0, 150.0])
+    for step in range(steps):
+        last = truth[-1]
+        new = np.array([last[0] + np.cos(last[2]) * 0.9, last[1] + np.sin(last[2]) * 0.9, last[2] + rng.uniform(-0.5, 0.5)])
+        truth.append(new); n = len(truth) - 1
+        g.add_node_xyt(new + rng.normal(0, [0.2, 0.2, 0.05]))
+        c, s_ = np.cos(last[2]), np.sin(last[2]); dx, dy = new[0] - last[0], new[1] - last[1]
+        g.add_factor_xyt(n - 1, n, np.array([c * dx + s_ * dy, -s_ * dx + c * dy, new[2] - last[2]]) + rng.normal(0, [0.03, 0.03, 0.01]), W)
+        if step % 9 == 4:                                   # a GPS-like prior on the new pose and one on an older pose
+            g.add_factor_xytpos(n, new + rng.normal(0, [0.05, 0.05, 0.02]), np.diag([25.0, 25.0, 40.0]))
+            o = int(rng.integers(0, n))
+            g.add_factor_xytpos(o, truth[o] + rng.normal(0, [0.05, 0.05, 0.02]), np.diag([25.0, 25.0, 40.0]))
+        p.c.batch_time = 1e300
+        g.cholesky_inc(p)
+        trace.append((g.chi2(), g.states()))
+    p.destroy(); g.destroy()
+    return trace
+
+
+def test_priors_added_between_incremental_calls_match_the_live_reference(lib, reflib):
+    ours = _growth_with_late_priors(lib)
+    ref = _growth_with_late_priors(reflib)
+    for k, ((c1, s1), (c2, s2)) in enumerate(zip(ours, ref)):
+        assert abs(c1 - c2) <= 1e-6 * max(c2, 1.0), (k, c1, c2)
+        assert np.max(np.abs(s1 - s2)) < 1e-6, k
+
+
 @pytest.mark.parametrize("seed,nthreshold", [(1, 25), (2, 10 ** 6), (3, 8)])
 def test_random_incremental_growth_matches_the_live_reference(lib, reflib, seed, nthreshold):
     """irregular incremental use (several poses per call, loop closures in both orientations, frequent or no batch

@@ -15,6 +15,8 @@ print("M3500 ms_per_step %.4f  it/s %.1f  factorise_ms %.4f  parity %.2e  first_
 print("  kernels ms/step:", d["kernels_ms_per_step"])
 print("  launches/step  :", d["kernel_launches_per_step"])
 print("  roofline:", {k: d["roofline"][k] for k in ("kernel", "achieved", "unit", "frac", "avg_launch_us")})
+if "api" in d:
+    print("  api:", json.dumps(d["api"]))
 if "lattice100k" in d:
     L = d["lattice100k"]
     print("lattice100k:", {k: L[k] for k in L if k != "workload"})
