@@ -14,6 +14,14 @@
 
 extern "C" {
 
+// replaces aprilsam.c:33-39 (the banner the reference's example programs print first, aprilsam.h:44)
+void APRILSAM_VERSION(void) {
+    printf("================\n");
+    printf("| APRILSAM 0.0 |   solver: aprilsam_amd (MI355X / gfx950)\n");
+    printf("================\n");
+    printf("\n");
+}
+
 // replaces aprilsam.c:45-64
 void april_graph_cholesky_param_init(april_graph_cholesky_param_t *param) {
     asam::drop_context(param);                 // a re-initialised param starts with no solver state

@@ -121,6 +121,29 @@ template <class T> struct HBuf {
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+// staging of the small per-step table updates of the incremental path: see k_apply_patches
+struct PatchList {
+    HBuf<char> buf; std::vector<Patch> hdr; size_t used = 0;
+    void reset() { hdr.clear(); used = 0; }
+    void add(void *dst, const void *src, size_t bytes) {
+        if (!bytes) return;
+        const size_t off = (used + 15) & ~(size_t)15;
+        buf.need(off + bytes + 64, true);
+        memcpy(buf.p + off, src, bytes);
+        hdr.push_back(Patch{ dst, (long long)off, (long long)bytes });
+        used = off + bytes;
+    }
+    // appends the header behind the payload and launches the scatter kernel (nothing to do: no launch)
+    void launch(hipStream_t s) {
+        if (hdr.empty()) return;
+        const size_t hoff = (used + 63) & ~(size_t)63, hbytes = hdr.size() * sizeof(Patch);
+        buf.need(hoff + hbytes, true);
+        memcpy(buf.p + hoff, hdr.data(), hbytes);
+        hipLaunchKernelGGL(k_apply_patches, dim3((unsigned)hdr.size()), dim3(TPB), 0, s, (const Patch *)(buf.p + hoff), (const char *)buf.p);
+    }
+    void release() { buf.release(); hdr.clear(); used = 0; }
+};
+
 // ------------------------------------------------------------------------------------------------------
 // packed graph (SoA, host pinned + device) — one per april_graph_t pointer
 // ------------------------------------------------------------------------------------------------------
@@ -176,13 +199,14 @@ static inline int zsize(const zarray_t *z) { return z ? z->size : 0; }
 // (nodes, z, W: 104 bytes) and only what changed is copied and uploaded again; a changed endpoint or factor kind
 // restarts the pack.  Option trust_factor_cache = 1 skips the comparison for factors whose object pointer is unchanged
 // (z / W of a packed factor are then treated as immutable).
-static void pack_factors(GraphPack &gp, const april_graph_t *g) {
+static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_old = true) {
+    const bool trust = g_opt.trust_factor_cache || !validate_old;      // (incremental calls never re-read old factors, aprilsam.c:508-511)
     const int F = zsize(g->factors);
     april_graph_factor_t **fs = (april_graph_factor_t **)g->factors->data;
     const int N = zsize(g->nodes);
     int from = gp.F;
     bool valid = from <= F && (int)gp.fptr.size() == from;
-    if (valid && g_opt.trust_factor_cache) valid = from == 0 || memcmp(gp.fptr.data(), fs, sizeof(void *) * from) == 0;
+    if (valid && trust) valid = from == 0 || memcmp(gp.fptr.data(), fs, sizeof(void *) * from) == 0;
     if (!valid) { from = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; gp.is_host.clear(); }
     gp.h_fa.need(F, true); gp.h_fb.need(F, true); gp.h_z.need((size_t)3 * F, true); gp.h_W.need((size_t)9 * F, true);
     gp.fptr.resize(F); gp.is_host.resize(F, 0);
@@ -201,7 +225,7 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g) {
         if (*a < 0 || *a >= N || *b >= N || *a == *b) { fprintf(stderr, "aprilsam_amd: FATAL: factor %d references node out of range\n", i); abort(); }
         return host_eval;
     };
-    if (from > 0 && !g_opt.trust_factor_cache) {
+    if (from > 0 && !trust) {
         // content check of the packed prefix; dirty range [lo, hi) is uploaded again by upload_factors
         int lo = from, hi = 0;
         bool restart = false;
@@ -415,6 +439,7 @@ struct Context {
     std::vector<int> base_tab;                     // host copy of the launch tables of the base plan
     std::vector<int> inc_slot_blk, inc_slot_rhs;   // slots of the factors added since the base plan (3 / 2 per factor)
     RefModel model;                       // the reference's tree / counters (refmodel.cpp), rebuilt lazily after a batch
+    PatchList patches;                    // per-step table updates of the incremental fast path
     int batch_factors = 0;                // #factors at the last batch step
     // look-ahead: the "rest" part of the wide trailing updates runs on a side stream (enqueue_big_steps)
     hipStream_t s2 = nullptr; std::vector<hipEvent_t> la_ev; size_t la_next = 0;
@@ -432,7 +457,7 @@ struct Context {
     double lambda_val = -1; int lambda_N = -1;     // what d_lambda currently holds (uniform batch value), -1: unknown
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
-        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release();
+        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release();
         if (gexec) (void)hipGraphExecDestroy(gexec);
         gexec = nullptr;
         if (gexec_api) (void)hipGraphExecDestroy(gexec_api);
@@ -1094,30 +1119,45 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh;
         if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
     }
-    // ---- 4. uploads ------------------------------------------------------------------------------------------------
-    if (!st_i32.empty()) HIPCHECK(hipMemcpyAsync(c.d_i32.p + I.i32_used, st_i32.data(), st_i32.size() * 4, hipMemcpyHostToDevice, s));
-    if (!st_dest.empty()) HIPCHECK(hipMemcpyAsync(c.d_dest.p + I.dest_used, st_dest.data(), st_dest.size() * sizeof(DestRec), hipMemcpyHostToDevice, s));
-    if (!st_child.empty()) HIPCHECK(hipMemcpyAsync(c.d_child.p + I.child_used, st_child.data(), st_child.size() * sizeof(ChildRec), hipMemcpyHostToDevice, s));
-    if (!tab.empty()) HIPCHECK(hipMemcpyAsync(c.d_tab.p + I.tab_used, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
+    // ---- 4. uploads: every table update of this step, the new factors and the new states through ONE pinned staging
+    //         buffer, scattered by one kernel (k_apply_patches) -- no copy-engine call on the path ---------------------------
+    PatchList &PL = c.patches;
+    PL.reset();
+    {   // new factors (what upload_factors would copy)
+        if (F > gp.F_cap) return false;                        // device arrays must grow: the re-plan path re-uploads
+        const int f0 = gp.F_on_device;
+        if (F > f0) {
+            PL.add(gp.d_fa.p + f0, gp.h_fa.p + f0, (size_t)(F - f0) * 4); PL.add(gp.d_fb.p + f0, gp.h_fb.p + f0, (size_t)(F - f0) * 4);
+            PL.add(gp.d_z.p + (size_t)3 * f0, gp.h_z.p + (size_t)3 * f0, (size_t)(F - f0) * 24);
+            PL.add(gp.d_W.p + (size_t)9 * f0, gp.h_W.p + (size_t)9 * f0, (size_t)(F - f0) * 72);
+            gp.F_on_device = F;
+        }
+    }
+    PL.add(c.d_i32.p + I.i32_used, st_i32.data(), st_i32.size() * 4);
+    PL.add(c.d_dest.p + I.dest_used, st_dest.data(), st_dest.size() * sizeof(DestRec));
+    PL.add(c.d_child.p + I.child_used, st_child.data(), st_child.size() * sizeof(ChildRec));
+    PL.add(c.d_tab.p + I.tab_used, tab.data(), tab.size() * 4);
     I.i32_used += (long long)st_i32.size(); I.dest_used += (long long)st_dest.size(); I.child_used += (long long)st_child.size();
-    for (int t : fd_dirty) HIPCHECK(hipMemcpyAsync(c.d_fd.p + t, &I.fd[t], sizeof(FrontDesc), hipMemcpyHostToDevice, s));
+    for (int t : fd_dirty) PL.add(c.d_fd.p + t, &I.fd[t], sizeof(FrontDesc));
     if (F > Fold) {
-        HIPCHECK(hipMemcpyAsync((int *)c.dp.slot_blk + (size_t)3 * Fold, new_slot_blk.data(), new_slot_blk.size() * 4, hipMemcpyHostToDevice, s));
-        HIPCHECK(hipMemcpyAsync((int *)c.dp.slot_rhs + (size_t)2 * Fold, new_slot_rhs.data(), new_slot_rhs.size() * 4, hipMemcpyHostToDevice, s));
-        HIPCHECK(hipMemcpyAsync(c.d_swap.p + Fold, new_swap.data(), new_swap.size(), hipMemcpyHostToDevice, s));
+        PL.add((int *)c.dp.slot_blk + (size_t)3 * Fold, new_slot_blk.data(), new_slot_blk.size() * 4);
+        PL.add((int *)c.dp.slot_rhs + (size_t)2 * Fold, new_slot_rhs.data(), new_slot_rhs.size() * 4);
+        PL.add(c.d_swap.p + Fold, new_swap.data(), new_swap.size());
     }
     if (N > Nold) {
         std::vector<int> &ids = I.st_ids; std::vector<double> &zeros = I.st_zeros;
         ids.resize(N - Nold); zeros.assign(N - Nold, 0.0);
         for (int i = Nold; i < N; i++) ids[i - Nold] = i;
-        HIPCHECK(hipMemcpyAsync(c.d_pos.p + Nold, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, s));
-        HIPCHECK(hipMemcpyAsync(c.d_lambda.p + Nold, zeros.data(), zeros.size() * 8, hipMemcpyHostToDevice, s));
+        PL.add(c.d_pos.p + Nold, ids.data(), ids.size() * 4);
+        PL.add(c.d_lambda.p + Nold, zeros.data(), zeros.size() * 8);
+        c.lambda_N = -1;
         P.perm.resize(N); P.pos.resize(N);
         for (int i = Nold; i < N; i++) { P.perm[i] = i; P.pos[i] = i; }
     }
+    PL.launch(s);
+    hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
     // ---- 5. numeric: new factors linearised, dirty fronts level by level, full back substitution, update ---------------
     set_small_attr();
-    HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 16, s));
     if (F > Fold)
         hipLaunchKernelGGL(k_linearize, dim3((F - Fold + TPB - 1) / TPB), dim3(TPB), 0, s, Fold, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                            gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);      // new priors: at the node's current state
@@ -1145,7 +1185,8 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             if (bs_n[l] > 0)
                 hipLaunchKernelGGL(k_backsolve, dim3((unsigned)bs_n[l]), dim3(TPB), I.base_levels[l].solve_lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0);
     }
-    hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
+    hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
+                       gp.h_state.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);          // new states / dx / pivot flag straight into the pinned mirrors
     HIPCHECK(hipGetLastError());
     for (int t : fd_dirty) I.dirty[t] = 0;
     c.st.n_fronts = nF0 + 1; c.st.n_levels = I.nLev0 + 1;
@@ -1280,14 +1321,15 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     GraphPack &gp = pack_for(g);
     c.want_inc = true;
     const double t0 = now_ms();
-    pack_factors(gp, g);
-    pack_states(gp, g, true);
+    pack_factors(gp, g, false);
+    pack_states(gp, g, true, false);                 // pinned mirrors only: the fast path reads them from its first kernel
     const int N = gp.N, F = gp.F;
+    c.h_bad.need(4);
     const double tp1 = now_ms();
     if (!c.model.valid) c.model.batch(c.batch_nodes, c.batch_factors, gp.h_fa.p, gp.h_fb.p);      // lazily, after a batch step
     c.model.inc_begin(N, F, gp.h_fa.p, gp.h_fb.p);
     const double tp2 = now_ms();
-    upload_factors(gp);
+    if (F > gp.F_cap || !g_opt.inc_fast || !gp.host_idx.empty()) upload_factors(gp);     // (growing the device arrays re-uploads everything)
     if (!gp.host_idx.empty()) {       // new foreign factors are linearised now, at the host objects' current l_points
         eval_host_factors(gp, g, gp.host_evaluated);     // (aprilsam.c:508-542); older ones keep their evaluation
         upload_host_index(gp);
@@ -1300,6 +1342,9 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     const bool partial = c.model.naffected <= 5;     // aprilsam.c:755: otherwise the whole tree is walked
     bool reused = g_opt.inc_fast && gp.host_idx.empty() && inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, partial ? &visits : nullptr);
     if (!reused) {                // the step does not fit the frozen structure (or slack ran out): full re-plan
+        upload_factors(gp);
+        HIPCHECK(hipMemcpyAsync(gp.d_state.p, gp.h_state.p, (size_t)24 * N, hipMemcpyHostToDevice, gp.stream));
+        HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.h_lp.p, (size_t)24 * N, hipMemcpyHostToDevice, gp.stream));
         gp.d_upt.need((size_t)3 * F);
         HIPCHECK(hipMemcpyAsync(gp.d_upt.p, gp.h_upt.data(), (size_t)24 * F, hipMemcpyHostToDevice, gp.stream));
         prepare_plan(c, gp, g);
@@ -1311,9 +1356,11 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     }
     c.inc_F = F; c.inc_N = N;
     const double tp4 = now_ms();
-    HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
-    HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
-    HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, gp.stream));
+    if (!reused) {                // (the fast path's last kernel wrote states, dx and the pivot flag into the pinned mirrors itself)
+        HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
+        HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
+        HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, gp.stream));
+    }
     HIPCHECK(hipStreamSynchronize(gp.stream));
     const double tp5 = now_ms();
     c.st.not_spd = c.h_bad.p[0] != 0;

@@ -132,6 +132,8 @@ typedef struct april_graph_cholesky_param {
  * PART 2 — the drop-in entry points (same names, arguments and error behaviour as the reference)
  * ---------------------------------------------------------------------------------------------- */
 
+/* replaces aprilsam.c:33-39 (aprilsam.h:44): the banner the reference's example programs print first */
+void APRILSAM_VERSION(void);
 /* replaces aprilsam.c:45-64 */
 void april_graph_cholesky_param_init(april_graph_cholesky_param_t *param);
 /* replaces aprilsam.c:66-85 (frees the side context, the owned arrays AND param itself) */

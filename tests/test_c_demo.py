@@ -89,3 +89,44 @@ def test_tutorial_driver_matches_reference_golden(built, tmp_path, mode):
     for k, blk in enumerate(blocks):
         st = np.array([[float(v) for v in m] for m in re.findall(r"node_\d+ = \{([-0-9.]+), ([-0-9.]+), ([-0-9.]+)\}", blk)])
         assert st.shape == (k + 1, 3) and np.max(np.abs(st - G[f"states_{k}"])) < 0.0051
+
+
+# ---- INTEGRATION.md Option A, for real: the reference's OWN example programs on the GPU library --------------------
+# oracle/Makefile compiles /root/reference/examples/aprilsam_demo.c and aprilsam_tutorial.c where they lie, links them
+# with the reference's own objects minus aprilsam.o (the solver) and with libaprilsam_amd.so instead (oracle/_ref/, test
+# infrastructure, built in the container, travels to the GPU box).  Unresolved symbols of those programs that our
+# library satisfies: APRILSAM_VERSION, april_graph_cholesky_param_init / _destory, april_graph_cholesky, _inc.
+REF_DEMO = os.path.join(ROOT, "oracle", "_ref", "ref_demo_on_amd")
+REF_TUTORIAL = os.path.join(ROOT, "oracle", "_ref", "ref_tutorial_on_amd")
+
+
+@pytest.mark.gpu
+def test_reference_demo_program_linked_against_our_library_reproduces_its_own_trace(built, tmp_path):
+    """all 3500 poses of the M3500 demo, incremental mode, through the reference's unmodified main(): the printed
+    chi^2 after every step equals the trace the all-reference build printed (golden, deterministic schedule) -- which
+    also means the 49 batch fall-backs happened at the same steps"""
+    if not os.path.exists(REF_DEMO):
+        pytest.skip("oracle/_ref/ref_demo_on_amd not built (needs /root/reference at build time)")
+    txt = str(tmp_path / "m.txt")
+    datasets.write_vertex_edge_text(txt, *datasets.m3500_arrays())
+    r = subprocess.run([REF_DEMO, "--datapath", txt, "--nthreshold", "100", "--delta_xy", "0.1", "--delta_theta", "0.1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "aprilsam_amd" in r.stdout.splitlines()[1]                    # our banner: the solver really is this library
+    chi2 = np.array([float(x) for x in re.findall(r"Chi squared error: ([-0-9.eE+]+)", r.stdout)])
+    G = golden("m3500_inc_demo.npz")["chi2"]
+    assert len(chi2) == len(G) == 3500
+    assert np.max(np.abs(chi2 - G) / np.maximum(G, 1e-6)) < 1e-5          # printed with %f: 6 decimals
+    assert abs(chi2[-1] - 68.965608) < 2e-6                               # SURVEY.md section 6, deterministic schedule
+
+
+@pytest.mark.gpu
+def test_reference_tutorial_program_linked_against_our_library(built):
+    if not os.path.exists(REF_TUTORIAL):
+        pytest.skip("oracle/_ref/ref_tutorial_on_amd not built (needs /root/reference at build time)")
+    r = subprocess.run([REF_TUTORIAL], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    chi2 = np.array([float(x) for x in re.findall(r"Chi squared error: ([-0-9.eE+]+)", r.stdout)])
+    G = golden("tutorial_inc.npz")
+    assert len(chi2) == 6 and np.max(np.abs(chi2 - G["chi2"])) < 2e-6
+    assert abs(chi2[-1] - 7.805041) < 2e-6                                # SURVEY.md section 4
