@@ -398,7 +398,10 @@ struct IncState {
     std::vector<int> cur_nub;               // per front: current update blocks
     std::vector<long long> cur_cap;         // per front: doubles allocated at fd.off
     std::vector<char> dirty;
-    std::vector<int> f_level;               // base levels, TAIL = nLev0
+    std::vector<int> f_level;               // base levels, tail front i = nLev0 + i
+    std::vector<int> t_first, t_cnt;        // tail fronts: first pose id, own poses
+    std::vector<int> tf_of;                 // tail pose (id - Nb) -> its tail front
+    std::vector<std::vector<int>> kids;     // per front: children that are NOT in the base plan's child lists (children of tail fronts)
     std::vector<LevelPlan> base_levels;     // launch tables of all fronts per level for the back substitution
     // staging for the per-step uploads (members: the async copies read them until the step's final sync)
     std::vector<int> st_i32, st_tab, st_sb, st_sr, st_ids; std::vector<DestRec> st_dest; std::vector<ChildRec> st_child;
@@ -494,6 +497,8 @@ bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out)
 
 // slack reserved at plan upload so that the incremental path can append without reallocating device buffers
 constexpr int INC_NODES = 4096, INC_FACT = 16384, INC_I32 = 4 << 20, INC_DEST = 1 << 20, INC_CHILD = 1 << 18, INC_TAB = 1 << 20;
+constexpr int TAIL_POSES = 24;               // own poses per tail front of the incremental path (inc_fast_step)
+constexpr int MAX_TAIL_FRONTS = INC_NODES / TAIL_POSES + 8;
 constexpr long long INC_POOL_MIN = 8ll << 20;             // doubles (64 MB; the M3500 demo appends ~25 MB of regenerated fronts between two batch steps)
 
 // waves of a k_front_small workgroup (option small_threads)
@@ -629,7 +634,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.inc.i32_used = (long long)i32.size(); c.inc.dest_used = (long long)P.dest.size(); c.inc.child_used = (long long)P.ch_idx.size();
     for (int t = 0; t < P.nF; t++) fd[t].rows_begin = (int)(o_rows + P.f_rows_ptr[t]);
     for (size_t k = 0; k < P.ch_idx.size(); k++) ch[k].rel_begin = (int)(o_rel + P.f_rows_ptr[ch[k].pad]);
-    c.d_i32.need(i32.size() + INC_I32_); c.d_fd.need(fd.size() + 1); c.d_child.need(ch.size() + INC_CHILD_);
+    c.d_i32.need(i32.size() + INC_I32_); c.d_fd.need(fd.size() + 1 + (inc ? MAX_TAIL_FRONTS : 0)); c.d_child.need(ch.size() + INC_CHILD_);
     c.d_dest.need(std::max<size_t>(1, P.dest.size()) + INC_DEST_);
     HIPCHECK(hipMemcpyAsync(c.d_i32.p, i32.data(), i32.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_fd.p, fd.data(), fd.size() * sizeof(FrontDesc), hipMemcpyHostToDevice, s));
@@ -918,39 +923,48 @@ static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g, bool
 }
 
 // ------------------------------------------------------------------------------------------------------
-// incremental fast path: frozen base plan + TAIL front + regeneration of the dirty root paths only
+// incremental fast path: frozen base plan + a chain of small TAIL fronts + regeneration of the dirty root paths only.
+//
+// The plan of the last batch step stays frozen.  Poses added since are eliminated after every base pose, in id order,
+// grouped into tail fronts of at most TAIL_POSES poses (front ids nF0, nF0 + 1, ...; only the last one grows).  Every
+// front carries E = the tail poses in its structure beyond its own columns (base fronts: appended behind their frozen
+// base structure).  A new factor makes its owner front dirty and pushes its later endpoint into E along the assembly
+// path up to the front that owns it; a front whose E changed, that owns a new factor or that has a dirty child is
+// regenerated (descriptor, destination records with indirect source lists, child maps -- appended to device arenas
+// reserved at plan upload) and re-factorised; clean fronts keep their factors and Schur updates in HBM.  Small tail
+// fronts keep every regenerated front inside the single-workgroup LDS kernel: one launch per dirty front on the root
+// path instead of the multi-launch big-front path one ever-growing tail front ran into.
 // ------------------------------------------------------------------------------------------------------
+
 static void inc_prepare(Context &c) {        // after a full (re)plan: c.plan is the new base
     IncState &I = c.inc; const Plan &P = c.plan;
     I.Nb = P.N; I.Fb = P.F; I.nF0 = P.nF; I.nLev0 = P.nLevels;
     I.pos_front.assign(P.N, 0);
     for (int t = 0; t < P.nF; t++) for (int k = 0; k < P.f_nsb[t]; k++) I.pos_front[P.f_first[t] + k] = t;
-    I.parent.assign(P.f_parent.begin(), P.f_parent.end()); I.parent.push_back(-1);
-    I.E.assign(P.nF, {}); I.xfac.assign(P.nF + 1, {});
+    I.parent.assign(P.f_parent.begin(), P.f_parent.end());
+    I.E.assign(P.nF, {}); I.xfac.assign(P.nF, {});
     I.bf_ptr.assign(P.nF + 1, 0);
     for (int f = 0; f < P.F; f++) if (P.fac_front[f] >= 0) I.bf_ptr[P.fac_front[f] + 1]++;
     for (int t = 0; t < P.nF; t++) I.bf_ptr[t + 1] += I.bf_ptr[t];
     I.bf_idx.resize(P.F);
     { std::vector<int> fill(I.bf_ptr.begin(), I.bf_ptr.end() - 1); for (int f = 0; f < P.F; f++) if (P.fac_front[f] >= 0) I.bf_idx[fill[P.fac_front[f]]++] = f; }
-    I.rel_begin.assign(P.nF + 1, 0); I.cur_nub.assign(P.nF + 1, 0); I.cur_cap.assign(P.nF + 1, 0);
+    I.rel_begin.assign(P.nF, 0); I.cur_nub.assign(P.nF, 0); I.cur_cap.assign(P.nF, 0);
     for (int t = 0; t < P.nF; t++) { I.rel_begin[t] = (int)(I.o_rel + P.f_rows_ptr[t]); I.cur_nub[t] = P.f_nub[t]; I.cur_cap[t] = (long long)P.rows(t) * P.cols(t); }
-    I.dirty.assign(P.nF + 1, 0);
-    I.f_level.assign(P.f_level.begin(), P.f_level.end()); I.f_level.push_back(P.nLevels);
-    I.fd.resize(P.nF + 1);
-    FrontDesc &T = I.fd[P.nF];
-    memset(&T, 0, sizeof(T));
-    T.first = P.N; T.parent = -1;
+    I.dirty.assign(P.nF, 0);
+    I.f_level.assign(P.f_level.begin(), P.f_level.end());
+    I.fd.resize(P.nF);
+    I.t_first.clear(); I.t_cnt.clear(); I.tf_of.clear(); I.kids.assign(P.nF, {});
     I.base_levels = c.levels;
     c.inc_slot_blk.clear(); c.inc_slot_rhs.clear();
     I.ready = true;
 }
 
-// Regenerate the dirty part of the plan for nodes [.., N) / factors [Fold, F) and run the numeric phase on it.
+// Regenerate the dirty part of the plan for nodes [Nold, N) / factors [Fold, F) and run the numeric phase on it.
 // Returns false (nothing enqueued) when the step does not fit the frozen structure or the reserved slack.
 static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int Nold, const std::vector<RefModel::Visit> *needed) {
     IncState &I = c.inc; Plan &P = c.plan;
     if (!I.ready || N < I.Nb || Fold < I.Fb) return false;
-    const int Nb = I.Nb, nF0 = I.nF0, TAIL = nF0, m = N - Nb;
+    const int Nb = I.Nb, nF0 = I.nF0, m = N - Nb;
     if (m > I.cap_nodes - 8 || F - I.Fb > I.cap_fact - 8 || m < 1) return false;
     const int *fa = gp.h_fa.p, *fb = gp.h_fb.p;
     hipStream_t s = gp.stream;
@@ -960,36 +974,75 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         const int *it = std::lower_bound(b, e, p);
         return (it == e || *it != p) ? -1 : P.f_nsb[t] + (int)(it - b);
     };
+    // ---- 0. new poses join the last tail front, or open the next one --------------------------------------------------
+    auto n_tail = [&]() { return (int)I.t_first.size(); };
+    for (int k = std::max(Nold, Nb); k < N; k++) {
+        if (I.t_first.empty() || I.t_cnt.back() >= TAIL_POSES) {
+            if (n_tail() >= MAX_TAIL_FRONTS - 1) return false;
+            I.t_first.push_back(k); I.t_cnt.push_back(0);
+            const int t = nF0 + n_tail() - 1;
+            I.parent.push_back(-1); I.E.emplace_back(); I.xfac.emplace_back(); I.rel_begin.push_back(0); I.cur_nub.push_back(0); I.cur_cap.push_back(0);
+            I.dirty.push_back(0); I.f_level.push_back(I.nLev0 + n_tail() - 1); I.kids.emplace_back();
+            I.fd.emplace_back(); memset(&I.fd[t], 0, sizeof(FrontDesc));
+            I.fd[t].first = k; I.fd[t].parent = -1;
+        }
+        I.t_cnt.back()++;
+        I.tf_of.push_back(nF0 + n_tail() - 1);
+        I.dirty[nF0 + n_tail() - 1] = 1;                 // its own columns changed
+    }
+    const int nT = n_tail(), nFr = nF0 + nT;
+    auto is_tail = [&](int t) { return t >= nF0; };
+    auto owns = [&](int t, int node) {                 // node (a TAIL pose) among the own columns of front t?
+        return is_tail(t) && node >= I.t_first[t - nF0] && node < I.t_first[t - nF0] + I.t_cnt[t - nF0];
+    };
+    auto set_parent = [&](int t, int par) {
+        if (I.parent[t] == par) return;
+        if (I.parent[t] >= nF0) { auto &kd = I.kids[I.parent[t]]; kd.erase(std::find(kd.begin(), kd.end(), t)); }
+        I.parent[t] = par;
+        if (par >= nF0) { auto &kd = I.kids[par]; kd.insert(std::lower_bound(kd.begin(), kd.end(), t), t); }
+    };
+    // tail pose k enters the structure of front t and of every front above it, up to the front that owns k.  Fronts
+    // without a base parent hang below the tail front that owns the first tail pose of their structure.
+    bool unfit = false;
+    auto add_struct = [&](int t, int k) {
+        while (t >= 0 && !owns(t, k)) {
+            auto &E = I.E[t];
+            auto it = std::lower_bound(E.begin(), E.end(), k);
+            if (it == E.end() || *it != k) { E.insert(it, k); I.dirty[t] = 1; }
+            if (is_tail(t) || P.f_parent[t] < 0) {
+                const int par = I.tf_of[E.front() - Nb];
+                if (I.parent[t] >= 0 && I.parent[t] != par) { unfit = true; return; }     // re-parenting a front with structure: re-plan
+                set_parent(t, par);
+            }
+            t = I.parent[t];
+        }
+    };
     // ---- 1. owners of the new factors, tail rows along root paths ----------------------------------------------
     for (int f = Fold; f < F; f++) {
         const int a = fa[f], b = fb[f];
         const bool ta = a >= Nb, tb = b >= Nb;
         int owner;
-        if (b < 0) owner = ta ? TAIL : I.pos_front[P.pos[a]];
-        else if (ta && tb) owner = TAIL;
+        if (b < 0) owner = ta ? I.tf_of[a - Nb] : I.pos_front[P.pos[a]];
+        else if (ta && tb) { owner = I.tf_of[std::min(a, b) - Nb]; add_struct(owner, std::max(a, b)); }
         else if (ta != tb) {
             const int j = ta ? b : a, k = ta ? a : b;
             owner = I.pos_front[P.pos[j]];
-            for (int t = owner; t != TAIL; t = I.parent[t]) {
-                auto &E = I.E[t];
-                auto it = std::lower_bound(E.begin(), E.end(), k);
-                if (it == E.end() || *it != k) { E.insert(it, k); I.dirty[t] = 1; }
-                if (I.parent[t] < 0) I.parent[t] = TAIL;
-            }
+            add_struct(owner, k);
         } else {
             const int pa = P.pos[a], pb = P.pos[b];
             owner = I.pos_front[std::min(pa, pb)];
             if (local_base(owner, std::max(pa, pb)) < 0) return false;       // would change the frozen structure
         }
+        if (unfit) return false;
         I.xfac[owner].push_back(f);
         I.dirty[owner] = 1;
     }
-    I.dirty[TAIL] = 1;
-    for (int t = 0; t < nF0; t++) if (I.dirty[t] && I.parent[t] >= 0) I.dirty[I.parent[t]] = 1;
+    for (int t = 0; t < nFr; t++) if (I.dirty[t] && I.parent[t] >= 0) I.dirty[I.parent[t]] = 1;     // (parents have larger ids)
     // ---- 2. regenerate dirty fronts (children before parents) ----------------------------------------------------
     std::vector<int> &st_i32 = I.st_i32; std::vector<DestRec> &st_dest = I.st_dest; std::vector<ChildRec> &st_child = I.st_child;
     st_i32.clear(); st_dest.clear(); st_child.clear();
-    std::vector<std::vector<int>> lev_dirty(I.nLev0 + 1);
+    const int nLev = I.nLev0 + nT;
+    std::vector<std::vector<int>> lev_dirty(nLev);
     std::vector<int> fd_dirty;
     std::vector<int> &new_slot_blk = I.st_sb, &new_slot_rhs = I.st_sr; std::vector<unsigned char> &new_swap = I.st_sw;
     new_slot_blk.assign((size_t)3 * (F - Fold), -1); new_slot_rhs.assign((size_t)2 * (F - Fold), -1); new_swap.assign(F - Fold, 0);
@@ -999,32 +1052,38 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         for (int k = 0; k < 2; k++) new_slot_rhs[(size_t)2 * (f - Fold) + k] = c.inc_slot_rhs[(size_t)2 * (f - I.Fb) + k] = I.slots_used++;
     }
     const long long i32_base = I.i32_used, dest_base = I.dest_used, child_base = I.child_used;
-    auto tail_children = [&]() { std::vector<int> v; for (int t = 0; t < nF0; t++) if (I.parent[t] == TAIL) v.push_back(t); return v; };
     struct Ent { int col, row, f, k, slot; };
     std::vector<Ent> ents;
-    for (int t = 0; t <= TAIL; t++) {
+    auto nsb_of = [&](int t) { return is_tail(t) ? I.t_cnt[t - nF0] : P.f_nsb[t]; };
+    auto nub0_of = [&](int t) { return is_tail(t) ? 0 : P.f_nub[t]; };
+    for (int t = 0; t < nFr; t++) {
         if (!I.dirty[t]) continue;
-        const bool is_tail = t == TAIL;
-        const int nsb = is_tail ? m : P.f_nsb[t], nub0 = is_tail ? 0 : P.f_nub[t];
-        const std::vector<int> empty;
-        const std::vector<int> &E = is_tail ? empty : I.E[t];
+        const bool tail = is_tail(t);
+        const int nsb = nsb_of(t), nub0 = nub0_of(t);
+        const std::vector<int> &E = I.E[t];
         const int nub = nub0 + (int)E.size(), nbc = nsb + nub;
         const long long need = (long long)(3 * (nbc + 1)) * (3 * nbc);
         FrontDesc &D = I.fd[t];
         if (need > I.cur_cap[t]) {
+            // growing fronts (the last tail front, fronts collecting tail rows) get head-room: no new array every step
+            const int gb = tail ? std::max(nbc + 4, TAIL_POSES + (int)E.size() + 4) : nbc + 4;
+            const long long want = (long long)(3 * (gb + 1)) * (3 * gb);
             const long long off = (I.pool_used + 31) & ~31ll;
-            if (off + need > I.pool_cap) return false;
-            D.off = off; I.pool_used = off + need; I.cur_cap[t] = need;
+            if (off + want > I.pool_cap) return false;
+            D.off = off; I.pool_used = off + want; I.cur_cap[t] = want;
         }
         D.nsb = nsb; D.nub = nub; I.cur_nub[t] = nub;
-        if (is_tail) D.first = Nb;
+        if (tail) D.first = I.t_first[t - nF0];
         // struct rows (positions): base struct then tail nodes (position of a tail node = its id)
         D.rows_begin = (int)(i32_base + (long long)st_i32.size());
-        if (!is_tail) st_i32.insert(st_i32.end(), P.f_rows.begin() + P.f_rows_ptr[t], P.f_rows.begin() + P.f_rows_ptr[t + 1]);
+        if (!tail) st_i32.insert(st_i32.end(), P.f_rows.begin() + P.f_rows_ptr[t], P.f_rows.begin() + P.f_rows_ptr[t + 1]);
         st_i32.insert(st_i32.end(), E.begin(), E.end());
         auto local = [&](int node) -> int {            // local block index of a node in this front
-            if (is_tail) return node - Nb;
-            if (node >= Nb) { auto it = std::lower_bound(E.begin(), E.end(), node); return nsb + nub0 + (int)(it - E.begin()); }
+            if (node >= Nb) {
+                if (tail && node < D.first + nsb) return node - D.first;
+                auto it = std::lower_bound(E.begin(), E.end(), node);
+                return nsb + nub0 + (int)(it - E.begin());
+            }
             return local_base(t, P.pos[node]);
         };
         // destination records: only fronts that own factors added since the batch need new ones
@@ -1042,7 +1101,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
                     ents.push_back({ lb, lb, f, 2, sb[2] }); ents.push_back({ lb, -1, f, 4, sr[1] });
                 }
             };
-            if (!is_tail) for (int q = I.bf_ptr[t]; q < I.bf_ptr[t + 1]; q++) add_factor(I.bf_idx[q]);
+            if (!tail) for (int q = I.bf_ptr[t]; q < I.bf_ptr[t + 1]; q++) add_factor(I.bf_idx[q]);
             for (int f : I.xfac[t]) add_factor(f);
             std::sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) {
                 if (x.col != y.col) return x.col < y.col;
@@ -1060,17 +1119,16 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             D.dest_end = (int)(dest_base + (long long)st_dest.size());
         }
         // children: records + block maps into this front's (possibly longer) row list
-        std::vector<int> kids_tail;
         const int *kb, *ke;
-        if (is_tail) { kids_tail = tail_children(); kb = kids_tail.data(); ke = kb + kids_tail.size(); }
+        if (tail) { kb = I.kids[t].data(); ke = kb + I.kids[t].size(); }
         else { kb = P.ch_idx.data() + P.ch_ptr[t]; ke = P.ch_idx.data() + P.ch_ptr[t + 1]; }
         D.ch_begin = (int)(child_base + (long long)st_child.size());
         for (const int *kp = kb; kp != ke; kp++) {
             const int ch = *kp;
-            const int cnsb = P.f_nsb[ch], cnub0 = P.f_nub[ch];
+            const int cnsb = nsb_of(ch), cnub0 = nub0_of(ch);
             const std::vector<int> &Ec = I.E[ch];
             I.rel_begin[ch] = (int)(i32_base + (long long)st_i32.size());
-            if (!is_tail) st_i32.insert(st_i32.end(), P.f_rel.begin() + P.f_rows_ptr[ch], P.f_rel.begin() + P.f_rows_ptr[ch + 1]);
+            if (!tail) st_i32.insert(st_i32.end(), P.f_rel.begin() + P.f_rows_ptr[ch], P.f_rel.begin() + P.f_rows_ptr[ch + 1]);
             for (int k : Ec) st_i32.push_back(local(k));
             ChildRec r;
             r.cnu = cnub0 + (int)Ec.size(); r.cR = 3 * (cnsb + r.cnu + 1);
@@ -1084,21 +1142,25 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         lev_dirty[I.f_level[t]].push_back(t);
     }
     if (I.i32_used + (long long)st_i32.size() > (long long)c.d_i32.cap || I.dest_used + (long long)st_dest.size() > (long long)c.d_dest.cap ||
-        I.child_used + (long long)st_child.size() > (long long)c.d_child.cap || (size_t)9 * I.slots_used > c.d_H.cap) return false;
-    // ---- 3. launch tables of the dirty fronts (transient region behind the base tables) + back-substitution LDS -----
-    std::vector<int> &tab = I.st_tab; tab.clear(); std::vector<LevelPlan> dl(I.nLev0 + 1);
-    auto dims = [&](int t, int *nsb, int *nub) { *nsb = t == TAIL ? m : P.f_nsb[t]; *nub = I.cur_nub[t]; };
-    for (int l = 0; l <= I.nLev0; l++) if (!lev_dirty[l].empty()) build_level(dl[l], lev_dirty[l], tab, dims);
-    std::vector<int> bs_off(I.nLev0, 0), bs_n(I.nLev0, 0);       // restricted back substitution: fronts per level
+        I.child_used + (long long)st_child.size() > (long long)c.d_child.cap || (size_t)9 * I.slots_used > c.d_H.cap || (size_t)nFr > c.d_fd.cap) return false;
+    // ---- 3. launch tables of the dirty fronts (transient region behind the base tables) + back-substitution lists -----
+    std::vector<int> &tab = I.st_tab; tab.clear(); std::vector<LevelPlan> dl(nLev);
+    auto dims = [&](int t, int *nsb, int *nub) { *nsb = nsb_of(t); *nub = I.cur_nub[t]; };
+    for (int l = 0; l < nLev; l++) if (!lev_dirty[l].empty()) build_level(dl[l], lev_dirty[l], tab, dims);
+    // back substitution: tail fronts one by one (last first), then the base levels; restricted to the fronts that hold a
+    // visited pose (and their ancestors) when the reference only walks the marked root paths
+    I.need.assign(nFr, needed ? 0 : 1);
     if (needed) {
-        I.need.assign(nF0 + 1, 0);
         for (const RefModel::Visit &v : *needed) {
-            int t = v.node >= Nb ? TAIL : I.pos_front[P.pos[v.node]];
-            while (t >= 0 && t != TAIL && !I.need[t]) { I.need[t] = 1; t = I.parent[t]; }
+            int t = v.node >= Nb ? I.tf_of[v.node - Nb] : I.pos_front[P.pos[v.node]];
+            while (t >= 0 && !I.need[t]) { I.need[t] = 1; t = I.parent[t]; }
         }
-        for (int l = 0; l < I.nLev0; l++) bs_off[l] = -1;
-        for (int l = I.nLev0 - 1; l >= 0; l--) {
-            bs_off[l] = (int)(I.tab_used + (long long)tab.size());
+    }
+    std::vector<int> bs_off(nLev, -1), bs_n(nLev, 0);
+    for (int l = nLev - 1; l >= 0; l--) {
+        bs_off[l] = (int)(I.tab_used + (long long)tab.size());
+        if (l >= I.nLev0) { const int t = nF0 + (l - I.nLev0); if (I.need[t]) { tab.push_back(t); bs_n[l] = 1; } }
+        else if (needed) {
             for (int k = I.base_levels[l].all_off; k < I.base_levels[l].all_off + I.base_levels[l].n_all; k++) {
                 const int t = c.base_tab[k];
                 if (I.need[t]) { tab.push_back(t); bs_n[l]++; }
@@ -1106,7 +1168,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         }
     }
     if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return false;
-    for (int l = 0; l <= I.nLev0; l++) {
+    for (int l = 0; l < nLev; l++) {
         if (lev_dirty[l].empty()) continue;
         LevelPlan &L = dl[l];
         const int sh = (int)I.tab_used;
@@ -1119,6 +1181,9 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh;
         if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
     }
+    auto solve_lds_of = [&](int t) { return (size_t)(3 * (nsb_of(t) + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8; };
+    for (int t = 0; t < nFr; t++) if (I.need[t] && solve_lds_of(t) > 160 * 1024) return false;
+    c.st.reserved0 = (int)fd_dirty.size();              // fronts regenerated by this step (tools/inc_hist.py)
     // ---- 4. uploads: every table update of this step, the new factors and the new states through ONE pinned staging
     //         buffer, scattered by one kernel (k_apply_patches) -- no copy-engine call on the path ---------------------------
     PatchList &PL = c.patches;
@@ -1156,12 +1221,12 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     }
     PL.launch(s);
     hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
-    // ---- 5. numeric: new factors linearised, dirty fronts level by level, full back substitution, update ---------------
+    // ---- 5. numeric: new factors linearised, dirty fronts level by level, back substitution, update ----------------------
     set_small_attr();
     if (F > Fold)
         hipLaunchKernelGGL(k_linearize, dim3((F - Fold + TPB - 1) / TPB), dim3(TPB), 0, s, Fold, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                            gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);      // new priors: at the node's current state
-    for (int l = 0; l <= I.nLev0; l++) {
+    for (int l = 0; l < nLev; l++) {
         if (lev_dirty[l].empty()) continue;
         const LevelPlan &L = dl[l];
         if (L.n_small) launch_front_small(c, L, s);
@@ -1171,25 +1236,22 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             enqueue_big_steps(c, L, s, [](int) {}, []() {});
         }
     }
-    {   // TAIL is the root of the back substitution; its launch list is the single dirty entry of the top level
-        const LevelPlan &L = dl[I.nLev0];
-        hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0);
-    }
-    if (!needed) {                                   // every pose is visited: all fronts, level by level
-        for (int l = I.nLev0 - 1; l >= 0; l--) {
+    for (int l = nLev - 1; l >= 0; l--) {
+        if (l >= I.nLev0 || needed) {
+            if (bs_n[l] > 0) {
+                const size_t lds = l >= I.nLev0 ? solve_lds_of(nF0 + l - I.nLev0) : I.base_levels[l].solve_lds;
+                hipLaunchKernelGGL(k_backsolve, dim3((unsigned)bs_n[l]), dim3(TPB), lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0);
+            }
+        } else {                                     // every pose is visited: all base fronts, level by level
             const LevelPlan &L = I.base_levels[l];
             hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0);
         }
-    } else {                                         // only the fronts holding a visited pose, and their ancestors
-        for (int l = I.nLev0 - 1; l >= 0; l--)
-            if (bs_n[l] > 0)
-                hipLaunchKernelGGL(k_backsolve, dim3((unsigned)bs_n[l]), dim3(TPB), I.base_levels[l].solve_lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0);
     }
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
                        gp.h_state.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);          // new states / dx / pivot flag straight into the pinned mirrors
     HIPCHECK(hipGetLastError());
     for (int t : fd_dirty) I.dirty[t] = 0;
-    c.st.n_fronts = nF0 + 1; c.st.n_levels = I.nLev0 + 1;
+    c.st.n_fronts = nFr; c.st.n_levels = nLev;
     return true;
 }
 
