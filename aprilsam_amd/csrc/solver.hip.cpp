@@ -434,6 +434,7 @@ struct Context {
     std::vector<hipEvent_t> k_ev; std::vector<int> k_ids;
     // incremental bookkeeping (aprilsam.c:741-751, 566-575)
     bool have_fact = false;               // a batch factorisation exists (reference: param->chol != NULL)
+    int plan_pin = 0;                     // pin_last the plan was built with
     bool want_inc = false;                // the param has been used incrementally: plan uploads reserve the append slack
     int batch_nodes = 0;                  // #nodes at the last batch step (those carry the Tikhonov term)
     IncState inc;
@@ -903,14 +904,14 @@ static double device_chi2(GraphPack &gp) {     // chi^2 at d_state; synchronises
 // make sure plan / device buffers match the packed graph; returns true if the plan was reused
 static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g, bool upload = true) {
     const int N = gp.N, F = gp.F;
-    bool same = c.have_plan && c.patN == N && (int)c.pat.size() == 2 * F && c.plan.leaf_nodes == g_opt.leaf_nodes;
+    bool same = c.have_plan && c.patN == N && (int)c.pat.size() == 2 * F && c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last;
     if (same) {
         for (int i = 0; i < F && same; i++) same = c.pat[2 * i] == gp.h_fa.p[i] && c.pat[2 * i + 1] == gp.h_fb.p[i];
     }
     if (same) return true;
     c.pat.resize((size_t)2 * F);
     for (int i = 0; i < F; i++) { c.pat[2 * i] = gp.h_fa.p[i]; c.pat[2 * i + 1] = gp.h_fb.p[i]; }
-    c.patN = N;
+    c.patN = N; c.plan_pin = g_opt.pin_last;
     std::vector<double> xy((size_t)2 * N);
     for (int i = 0; i < N; i++) { xy[2 * i] = gp.h_state.p[3 * i]; xy[2 * i + 1] = gp.h_state.p[3 * i + 1]; }
     const double tb0 = now_ms();
@@ -2258,6 +2259,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "lookahead") g_opt.lookahead = (int)v;
     else if (k == "inc_fast") g_opt.inc_fast = (int)v;
     else if (k == "block_factor") g_opt.block_factor = (int)v;
+    else if (k == "pin_last") g_opt.pin_last = (int)v;
     else return -1;
     return 0;
 }

@@ -7,6 +7,7 @@
 // tree, child->parent scatter maps, the factor->front assignment with deterministic gather lists, and a
 // level schedule (fronts of one level are independent => one batched kernel launch).
 #include "plan.h"
+#include "solver.h"
 
 #include <algorithm>
 #include <cassert>
@@ -43,7 +44,23 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
 
     // ---- nested dissection tree, post-order numbering ----------------------------------------------
     NDTree tree;
-    nested_dissection(N, ap, ai, xy, leaf_nodes, tree);
+    // Option pin_last = k ("recent poses last", the counterpart of the reference's constrained min-degree order,
+    // aprilsam.c:1021-1098, which keeps the newest pose and the poses around its neighbours at the end of the elimination
+    // order): the k highest pose ids are taken out of the dissection and form the ROOT front, so that a factor arriving at
+    // the newest poses only touches the root.  Measured on the incremental demo: tools/inc_hist.py -> profiles/.
+    const int pin = std::max(0, std::min(g_opt.pin_last, N - 1));
+    if (pin > 0) {
+        const int M = N - pin;
+        std::vector<int> ap2(M + 1, 0), ai2;
+        for (int i = 0; i < M; i++) { for (int e = ap[i]; e < ap[i + 1]; e++) if (ai[e] < M) ai2.push_back(ai[e]); ap2[i + 1] = (int)ai2.size(); }
+        nested_dissection(M, ap2, ai2, xy, leaf_nodes, tree);
+        NDTree::Node root;
+        for (int v = M; v < N; v++) root.verts.push_back(v);
+        root.children = tree.roots;
+        tree.nodes.push_back(std::move(root));
+        tree.roots.assign(1, (int)tree.nodes.size() - 1);
+    } else
+        nested_dissection(N, ap, ai, xy, leaf_nodes, tree);
     const int nT = (int)tree.nodes.size();
     P.nF = nT;
     P.perm.assign(N, -1); P.pos.assign(N, -1);

@@ -98,3 +98,25 @@ def test_lattice_plan_quality(lib):
     nnzL, flops = int(P.stats[3]), float(P.stats[4])
     assert nnzL < 62.9e6 and flops < 3.0e10
     assert P.nLevels <= 16
+
+
+@pytest.mark.parametrize("pin", [1, 8, 40])
+def test_pin_last_keeps_the_newest_poses_in_the_root_front(lib, oracle, pin):
+    """option pin_last ("recent poses last", cf. aprilsam.c:1021-1098): the k newest poses form the root front; the plan
+    stays a valid plan and the numeric emulation still solves the system"""
+    st, fa, fb, z, W = datasets.random_pose_graph(200, 120, 9)
+    N = len(st)
+    lib.set_option("pin_last", pin)
+    try:
+        P = PlanView(lib, N, fa, fb, xy=st[:, :2], leaf_nodes=8)
+    finally:
+        lib.set_option("pin_last", 0)
+    _check_structure(P, N, fa, fb)
+    root = P.nF - 1
+    assert P.front_parent[root] == -1 and P.front_nsb[root] == pin
+    assert sorted(P.perm[P.front_first[root]:].tolist()) == list(range(N - pin, N))
+    H, G = contributions(oracle, st, st, fa, fb, z, W, P.factor_swap)
+    lam = np.full(N, 1e-4)
+    dx = solve(P, H, G, lam).reshape(N, 3)[P.pos]
+    ref = oracle.solve_system(st, st, fa, fb, z, W, lam)
+    assert np.max(np.abs(dx - ref)) < 1e-7 * max(1.0, np.max(np.abs(ref)))
