@@ -72,6 +72,7 @@ static void load_env_options() {
         v = g_opt.lookahead; envd("APRILSAM_AMD_LOOKAHEAD", &v); g_opt.lookahead = (int)v;
         v = g_opt.inc_fast; envd("APRILSAM_AMD_INC_FAST", &v); g_opt.inc_fast = (int)v;
         v = g_opt.block_factor; envd("APRILSAM_AMD_BLOCK_FACTOR", &v); g_opt.block_factor = (int)v;
+        v = g_opt.fused_panel; envd("APRILSAM_AMD_FUSED_PANEL", &v); g_opt.fused_panel = (int)v;
     });
 }
 
@@ -376,6 +377,8 @@ struct LevelPlan {
     Launch asm_big{};                                          // k_assemble_big
     std::vector<Launch> syrka, syrkb;                          // look-ahead split of the wide update (modes 2, 3), same indexing as syrkw
     std::vector<Launch> panel, syrk, syrkw;                    // per panel step: diag+panel, narrow update, wide update (grid 0 unless the step closes an outer block)
+    std::vector<int> diag_slot0;                               // per panel step: first slot of its factored diagonal blocks in d_diag (multi-tile steps)
+    int wb_off = 0, n_wb = 0, n_diag_slots = 0;                // k_diag_writeback entries (3 ints each) of the level, slots used
     int all_off = 0, n_all = 0; size_t solve_lds = 0;          // every front (k_backsolve)
     Launch bs_gemv{};                                          // fronts whose update-row product is spread over workgroups first (k_backsolve_gemv)
 };
@@ -566,9 +569,15 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     L.asm_big = make((int)big.size(), [&](int t) { return asm_chunks(cols(t) / 3); });
     int steps = (3 * nsb_of(big[0]) + NB - 1) / NB;
     auto active = [&](int sidx) { int nact = 0; while (nact < (int)big.size() && 3 * nsb_of(big[nact]) > sidx * NB) nact++; return nact; };
+    std::vector<int> wb;
     for (int sidx = 0; sidx < steps; sidx++) {
         const int nact = active(sidx);
         L.panel.push_back(make(nact, [&](int t) { return panel_tiles(rows(t), 3 * nsb_of(t), sidx); }));
+        L.diag_slot0.push_back(L.n_diag_slots);
+        if (!L.panel.back().single) {           // multi-tile step: the factored diagonal blocks wait in d_diag until the level's write-back
+            for (int i = 0; i < nact; i++) { wb.push_back(big[i]); wb.push_back(sidx); wb.push_back(L.n_diag_slots + i); }
+            L.n_diag_slots += nact;
+        }
         L.syrk.push_back(make(nact, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), sidx, sidx + 1, 0); }));
         if ((sidx + 1) % OBP == 0 || sidx + 1 == steps) {
             const int s_lo = sidx / OBP * OBP;
@@ -586,6 +595,8 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
             L.syrka.push_back(Launch{ 0, 0, 0, 0, false }); L.syrkb.push_back(Launch{ 0, 0, 0, 0, false });
         }
     }
+    L.wb_off = (int)tab.size(); L.n_wb = (int)wb.size() / 3;
+    tab.insert(tab.end(), wb.begin(), wb.end());
 }
 
 // Per-rank layout of the front pool in a sharded run: a rank keeps the frontal arrays of the fronts it OWNS and, for
@@ -681,7 +692,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.inc.slots_used = P.n_slots;
     c.inc.ready = false;
     c.d_bad.need(4); c.h_bad.need(4);
-    { int mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, c.levels[l].n_big); c.d_diag.need((size_t)(mx + 64) * NB * (NB + 1)); }
+    { int mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max({ mx, c.levels[l].n_big, c.levels[l].n_diag_slots }); c.d_diag.need((size_t)(mx + 64) * NB * (NB + 1)); }
     c.st.n_fronts = P.nF; c.st.n_levels = P.nLevels; c.st.max_front_rows = P.max_rows;
     c.st.nnz_L = P.nnzL; c.st.flops_factor = P.flops; c.st.bytes_fronts = 8.0 * (double)pool_doubles;
 }
@@ -741,6 +752,11 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
             tic(K_PANEL_BIG);
             hipLaunchKernelGGL(k_diagpanel_big, dim3(pa.n), dim3(TPB), 0, s, c.dp, tab + pa.list_off, (int)k, c.d_pool.p, c.d_bad.p);
             toc();
+        } else if (g_opt.fused_panel) {   // several row tiles per front: every tile factors the diagonal block itself, one launch
+            tic(K_PANEL_BIG);
+            hipLaunchKernelGGL(k_diagpanel_multi, dim3(pa.grid), dim3(TPB), 0, s, c.dp, tab + pa.list_off, tab + pa.pre_off, pa.n, (int)k, c.d_pool.p,
+                               c.d_diag.p, L.diag_slot0[k], c.d_bad.p);
+            toc();
         } else {
             tic(K_DIAG_BIG);
             hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, tab + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
@@ -776,6 +792,11 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
         if (sb.grid > 0) { rest_done = c.la_event(); HIPCHECK(hipEventRecord(rest_done, c.s2)); }
     }
     if (rest_done) HIPCHECK(hipStreamWaitEvent(s, rest_done, 0));      // join: the next level reads the update blocks
+    if (g_opt.fused_panel && L.n_wb > 0) {       // the diagonal blocks parked by k_diagpanel_multi go into their fronts
+        tic(K_DIAG_BIG);
+        hipLaunchKernelGGL(k_diag_writeback, dim3(L.n_wb), dim3(TPB), 0, s, c.dp, tab + L.wb_off, c.d_pool.p, c.d_diag.p);
+        toc();
+    }
 }
 
 // kernels of one level of the factorisation (small LDS fronts, big multi-workgroup path)
@@ -1179,9 +1200,10 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrka) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrkb) { x.list_off += sh; x.pre_off += sh; }
-        L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh;
+        L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh; L.wb_off += sh;
         if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
     }
+    for (int l = 0; l < nLev; l++) if ((size_t)(std::max(dl[l].n_big, dl[l].n_diag_slots) + 64) * NB * (NB + 1) > c.d_diag.cap) return false;
     auto solve_lds_of = [&](int t) { return (size_t)(3 * (nsb_of(t) + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8; };
     for (int t = 0; t < nFr; t++) if (I.need[t] && solve_lds_of(t) > 160 * 1024) return false;
     c.st.reserved0 = (int)fd_dirty.size();              // fronts regenerated by this step (tools/inc_hist.py)
@@ -1942,7 +1964,7 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
     if (tab.empty()) tab.push_back(0);
     S.d_tab.need(tab.size());
     HIPCHECK(hipMemcpyAsync(S.d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, gp.stream));
-    { int mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, S.levels[l].n_big); c.d_diag.need((size_t)(mx + 64) * NB * (NB + 1)); }
+    { int mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max({ mx, S.levels[l].n_big, S.levels[l].n_diag_slots }); c.d_diag.need((size_t)(mx + 64) * NB * (NB + 1)); }
     // ---- factors owned by this rank's fronts, node ownership ----------------------------------------------------
     std::vector<int> fl;
     for (int f = 0; f < P.F; f++) if (P.fac_front[f] >= 0 && S.owner[P.fac_front[f]] == rank) fl.push_back(f);
@@ -2260,6 +2282,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "inc_fast") g_opt.inc_fast = (int)v;
     else if (k == "block_factor") g_opt.block_factor = (int)v;
     else if (k == "pin_last") g_opt.pin_last = (int)v;
+    else if (k == "fused_panel") g_opt.fused_panel = (int)v;
     else return -1;
     return 0;
 }
