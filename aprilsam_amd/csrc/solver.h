@@ -20,6 +20,8 @@ struct Options {
     int tp_lds_kb = 64;           // ... where only fronts up to this LDS size run fully in LDS (the rest: panel mode, more workgroups per CU)
     int lookahead = 0;            // 1: wide trailing updates split, next outer block columns first, the rest on a side stream (measured: no gain)
     int pin_last = 0;             // nested dissection keeps the pin_last newest poses out of the dissection: they form the root front ("recent poses last")
+    int batch_extend = 1;         // batch calls on a graph that only grew reuse the plan: appended poses become tail fronts, every front is re-factorised
+    int extend_tail_fronts = 8;   // ... until the tail has this many fronts (then: full re-plan)
     int fused_panel = 1;          // big fronts: diagonal block factored inside every row-tile workgroup of the panel kernel (0: k_diag_big + k_panel_big)
     int block_factor = 1;         // k_front_small: pivot chain of 16 columns at a time in registers (0: per 3x3 pivot through LDS)
     int panel_mode = 1;           // fronts too large for LDS whose own columns fit run in k_front_small's panel mode

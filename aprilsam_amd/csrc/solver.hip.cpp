@@ -73,6 +73,8 @@ static void load_env_options() {
         v = g_opt.inc_fast; envd("APRILSAM_AMD_INC_FAST", &v); g_opt.inc_fast = (int)v;
         v = g_opt.block_factor; envd("APRILSAM_AMD_BLOCK_FACTOR", &v); g_opt.block_factor = (int)v;
         v = g_opt.fused_panel; envd("APRILSAM_AMD_FUSED_PANEL", &v); g_opt.fused_panel = (int)v;
+        v = g_opt.batch_extend; envd("APRILSAM_AMD_BATCH_EXTEND", &v); g_opt.batch_extend = (int)v;
+        v = g_opt.extend_tail_fronts; envd("APRILSAM_AMD_EXTEND_TAIL_FRONTS", &v); g_opt.extend_tail_fronts = (int)v;
     });
 }
 
@@ -438,6 +440,7 @@ struct Context {
     // incremental bookkeeping (aprilsam.c:741-751, 566-575)
     bool have_fact = false;               // a batch factorisation exists (reference: param->chol != NULL)
     int plan_pin = 0;                     // pin_last the plan was built with
+    int same_topo_batches = 0;            // batch calls on an extended (base + tail fronts) plan whose topology did not change since the previous call
     bool want_inc = false;                // the param has been used incrementally: plan uploads reserve the append slack
     int batch_nodes = 0;                  // #nodes at the last batch step (those carry the Tikhonov term)
     IncState inc;
@@ -690,7 +693,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.inc.pool_used = pool_doubles; c.inc.pool_cap = (long long)c.d_pool.cap;
     c.d_H.need((size_t)9 * ((size_t)std::max(1, P.n_slots) + (size_t)5 * INC_FACT_)); c.d_x.need((size_t)3 * ((size_t)P.N + INC_NODES_));
     c.inc.slots_used = P.n_slots;
-    c.inc.ready = false;
+    c.inc.ready = false; c.inc.t_first.clear(); c.same_topo_batches = 0;
     c.d_bad.need(4); c.h_bad.need(4);
     { int mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max({ mx, c.levels[l].n_big, c.levels[l].n_diag_slots }); c.d_diag.need((size_t)(mx + 64) * NB * (NB + 1)); }
     c.st.n_fronts = P.nF; c.st.n_levels = P.nLevels; c.st.max_front_rows = P.max_rows;
@@ -925,7 +928,8 @@ static double device_chi2(GraphPack &gp) {     // chi^2 at d_state; synchronises
 // make sure plan / device buffers match the packed graph; returns true if the plan was reused
 static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g, bool upload = true) {
     const int N = gp.N, F = gp.F;
-    bool same = c.have_plan && c.patN == N && (int)c.pat.size() == 2 * F && c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last;
+    bool same = c.have_plan && c.patN == N && (int)c.pat.size() == 2 * F && c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last &&
+                c.inc.t_first.empty();        // (a plan extended by tail fronts is only driven by inc_fast_step)
     if (same) {
         for (int i = 0; i < F && same; i++) same = c.pat[2 * i] == gp.h_fa.p[i] && c.pat[2 * i + 1] == gp.h_fb.p[i];
     }
@@ -983,8 +987,13 @@ static void inc_prepare(Context &c) {        // after a full (re)plan: c.plan is
 
 // Regenerate the dirty part of the plan for nodes [Nold, N) / factors [Fold, F) and run the numeric phase on it.
 // Returns false (nothing enqueued) when the step does not fit the frozen structure or the reserved slack.
-static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int Nold, const std::vector<RefModel::Visit> *needed) {
+// batch_lambda >= 0: the same structures driven as a BATCH step (april_graph_cholesky on a graph that only grew since the
+// plan was made): every node re-linearised, every factor linearised, the Tikhonov term batch_lambda on every pose,
+// every front -- base and tail -- re-factorised, full back substitution.  Saves the nested dissection + symbolic analysis
+// + plan upload (6-7 ms on M3500) that a cold call pays, at the price of a less bushy tree for the appended poses.
+static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int Nold, const std::vector<RefModel::Visit> *needed, double batch_lambda = -1.0) {
     IncState &I = c.inc; Plan &P = c.plan;
+    const bool batch = batch_lambda >= 0;
     if (!I.ready || N < I.Nb || Fold < I.Fb) return false;
     const int Nb = I.Nb, nF0 = I.nF0, m = N - Nb;
     if (m > I.cap_nodes - 8 || F - I.Fb > I.cap_fact - 8 || m < 1) return false;
@@ -1168,11 +1177,17 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     // ---- 3. launch tables of the dirty fronts (transient region behind the base tables) + back-substitution lists -----
     std::vector<int> &tab = I.st_tab; tab.clear(); std::vector<LevelPlan> dl(nLev);
     auto dims = [&](int t, int *nsb, int *nub) { *nsb = nsb_of(t); *nub = I.cur_nub[t]; };
+    if (batch) {            // every front of every level, with its current dimensions
+        for (int l = 0; l < nLev; l++) {
+            if (l < I.nLev0) lev_dirty[l].assign(P.lev_fronts.begin() + P.lev_ptr[l], P.lev_fronts.begin() + P.lev_ptr[l + 1]);
+            else lev_dirty[l].assign(1, nF0 + l - I.nLev0);
+        }
+    }
     for (int l = 0; l < nLev; l++) if (!lev_dirty[l].empty()) build_level(dl[l], lev_dirty[l], tab, dims);
     // back substitution: tail fronts one by one (last first), then the base levels; restricted to the fronts that hold a
     // visited pose (and their ancestors) when the reference only walks the marked root paths
     I.need.assign(nFr, needed ? 0 : 1);
-    if (needed) {
+    if (needed && !batch) {
         for (const RefModel::Visit &v : *needed) {
             int t = v.node >= Nb ? I.tf_of[v.node - Nb] : I.pos_front[P.pos[v.node]];
             while (t >= 0 && !I.need[t]) { I.need[t] = 1; t = I.parent[t]; }
@@ -1181,6 +1196,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     std::vector<int> bs_off(nLev, -1), bs_n(nLev, 0);
     for (int l = nLev - 1; l >= 0; l--) {
         bs_off[l] = (int)(I.tab_used + (long long)tab.size());
+        if (batch) continue;                       // (the full tables built above serve the back substitution too)
         if (l >= I.nLev0) { const int t = nF0 + (l - I.nLev0); if (I.need[t]) { tab.push_back(t); bs_n[l] = 1; } }
         else if (needed) {
             for (int k = I.base_levels[l].all_off; k < I.base_levels[l].all_off + I.base_levels[l].n_all; k++) {
@@ -1237,16 +1253,25 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         ids.resize(N - Nold); zeros.assign(N - Nold, 0.0);
         for (int i = Nold; i < N; i++) ids[i - Nold] = i;
         PL.add(c.d_pos.p + Nold, ids.data(), ids.size() * 4);
-        PL.add(c.d_lambda.p + Nold, zeros.data(), zeros.size() * 8);
+        if (!batch) PL.add(c.d_lambda.p + Nold, zeros.data(), zeros.size() * 8);      // no Tikhonov term on poses added incrementally (aprilsam.c:508-542)
         c.lambda_N = -1;
         P.perm.resize(N); P.pos.resize(N);
         for (int i = Nold; i < N; i++) { P.perm[i] = i; P.pos[i] = i; }
     }
+    if (batch) {            // aprilsam.c:197-204: the Tikhonov term on every pose
+        c.h_lambda.assign(N, batch_lambda);
+        PL.add(c.d_lambda.p, c.h_lambda.data(), (size_t)N * 8);
+        c.lambda_N = -1;
+    }
     PL.launch(s);
-    hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
+    if (batch) hipLaunchKernelGGL(k_load_states, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.d_state.p, gp.d_lp.p);      // l_point <- state
+    else hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
     // ---- 5. numeric: new factors linearised, dirty fronts level by level, back substitution, update ----------------------
     set_small_attr();
-    if (F > Fold)
+    if (batch)
+        hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
+                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p);
+    else if (F > Fold)
         hipLaunchKernelGGL(k_linearize, dim3((F - Fold + TPB - 1) / TPB), dim3(TPB), 0, s, Fold, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                            gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);      // new priors: at the node's current state
     for (int l = 0; l < nLev; l++) {
@@ -1260,6 +1285,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         }
     }
     for (int l = nLev - 1; l >= 0; l--) {
+        if (batch) { launch_backsolve(c, dl[l], s, [](int) {}, []() {}); continue; }
         if (l >= I.nLev0 || needed) {
             if (bs_n[l] > 0) {
                 const size_t lds = l >= I.nLev0 ? solve_lds_of(nF0 + l - I.nLev0) : I.base_levels[l].solve_lds;
@@ -1271,9 +1297,13 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         }
     }
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
-                       gp.h_state.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);          // new states / dx / pivot flag straight into the pinned mirrors
+                       batch ? gp.h_lp.p : gp.h_state.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);          // new states / dx / pivot flag straight into the pinned mirrors
     HIPCHECK(hipGetLastError());
     for (int t : fd_dirty) I.dirty[t] = 0;
+    // the pattern folded into the device structures (a later batch call compares against it)
+    c.pat.resize((size_t)2 * F);
+    for (int f = Fold; f < F; f++) { c.pat[2 * f] = fa[f]; c.pat[2 * f + 1] = fb[f]; }
+    c.patN = N;
     c.st.n_fronts = nFr; c.st.n_levels = nLev;
     return true;
 }
@@ -1304,16 +1334,41 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         upload_host_index(gp);
     }
     const double t1 = now_ms();
-    const bool reused = prepare_plan(c, gp, g);
-    const double t2 = now_ms();
-    upload_factors(gp);
-    set_lambda(c, gp, param->tikhanov);
-    const double t3 = now_ms();
     const bool timing = g_opt.device_timing != 0;
-    // One graph launch: k_load_states pulls the packed states from the pinned mirror (state and, every node being
-    // re-linearised first, aprilsam.c:131-135, l_point), ..., k_update_states leaves new states (h_lp), dx and the pivot
-    // flag in pinned mirrors.  No copy-engine call on the path.
-    run_numeric(c, gp, timing, false, true);
+    // A graph that only GREW since the plan was made (the reference's demo in --batch_update_only mode, examples/
+    // aprilsam_demo.c:224-228; the batch fall-backs of an incremental run): instead of a new nested dissection + symbolic
+    // analysis + plan upload per call, the appended poses become tail fronts of the existing plan (the machinery of the
+    // incremental path) and EVERY front is re-factorised -- batch semantics on an extended plan.  A full re-plan follows
+    // when the tail has grown past extend_tail_fronts fronts, or when the topology stops changing (second call in a row).
+    bool hybrid = false, reused = false;
+    {
+        const int patF = (int)c.pat.size() / 2;
+        bool ext = g_opt.batch_extend && !timing && c.have_plan && c.inc.ready && gp.host_idx.empty() && N >= c.patN && F >= patF &&
+                   c.inc_N == c.patN && c.inc_F == patF && c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last;
+        for (int i = 0; i < patF && ext; i++) ext = c.pat[2 * i] == gp.h_fa.p[i] && c.pat[2 * i + 1] == gp.h_fb.p[i];
+        const bool grew = ext && (N > c.patN || F > patF);
+        if (grew) { c.want_inc = true; c.same_topo_batches = 0; }        // (plans made from now on reserve the append slack)
+        else if (ext && !c.inc.t_first.empty()) c.same_topo_batches++;
+        const int tails_after = (N - c.inc.Nb + TAIL_POSES - 1) / TAIL_POSES;
+        if (ext && N > c.inc.Nb && c.inc.cap_nodes > 0 && tails_after <= g_opt.extend_tail_fronts && (grew || (!c.inc.t_first.empty() && c.same_topo_batches <= 1))) {
+            if (F > gp.F_cap) upload_factors(gp);
+            c.h_bad.need(4);
+            hybrid = inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, nullptr, param->tikhanov > 0 ? param->tikhanov : 0.0);
+            reused = hybrid;
+        }
+    }
+    double t2 = now_ms(), t3 = t2;
+    if (!hybrid) {
+        reused = prepare_plan(c, gp, g);
+        t2 = now_ms();
+        upload_factors(gp);
+        set_lambda(c, gp, param->tikhanov);
+        t3 = now_ms();
+        // One graph launch: k_load_states pulls the packed states from the pinned mirror (state and, every node being
+        // re-linearised first, aprilsam.c:131-135, l_point), ..., k_update_states leaves new states (h_lp), dx and the pivot
+        // flag in pinned mirrors.  No copy-engine call on the path.
+        run_numeric(c, gp, timing, false, true);
+    }
     HIPCHECK(hipStreamSynchronize(gp.stream));
     const double t4 = now_ms();
     c.st.not_spd = c.h_bad.p[0] != 0;
@@ -1340,7 +1395,8 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         param->nreordering = N;
         param->factor_num = F;
         c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = false;
-        inc_prepare(c); c.inc_F = F; c.inc_N = N;
+        if (!hybrid) inc_prepare(c);                     // (an extended plan keeps its base + tail bookkeeping)
+        c.inc_F = F; c.inc_N = N;
         record_unary_points(gp, 0, F, gp.h_state.p);         // the linearisation point of this call
         if (param->delta_x) {                                                // aprilsam.c:363-366
             free(param->delta_x);
@@ -1436,10 +1492,11 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
         c.h_lambda.assign(N, 0.0);
         for (int i = 0; i < N; i++) if (c.plan.perm[i] < c.batch_nodes && param->tikhanov > 0) c.h_lambda[i] = param->tikhanov;
         HIPCHECK(hipMemcpyAsync(c.d_lambda.p, c.h_lambda.data(), (size_t)8 * N, hipMemcpyHostToDevice, gp.stream));
+        c.lambda_N = -1;                                  // (not the uniform batch value)
         run_numeric(c, gp, false, true);
         inc_prepare(c);
     }
-    c.inc_F = F; c.inc_N = N;
+    c.inc_F = F; c.inc_N = N; c.same_topo_batches = 0;
     const double tp4 = now_ms();
     if (!reused) {                // (the fast path's last kernel wrote states, dx and the pivot flag into the pinned mirrors itself)
         HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
@@ -1666,7 +1723,7 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
         // algorithmic bytes of a front: its L panel + update block written once, children's updates read once
         const double by = 8.0 * (ns * (ns + 1) / 2 + (nu + 1) * ns + (nu + 1) * (nu + 2) / 2);
         if (small) { flops[K_FRONT_SMALL] += fl; bytes[K_FRONT_SMALL] += by; }
-        else { flops[K_SYRK_BIG] += fl; bytes[K_SYRK_BIG] += by; }
+        else { flops[K_SYRK_BIG] += fl; bytes[K_SYRK_BIG] += by; bytes[K_ASSEMBLE_BIG] += by; }      // (assembly: the front written once, children's updates read once)
         bytes[K_BACKSOLVE] += 8.0 * (ns * (ns + 1) / 2 + nu * ns) + 16.0 * (ns + nu);
         flops[K_BACKSOLVE] += 2.0 * (ns * (ns + 1) / 2 + nu * ns);
     }
@@ -2283,6 +2340,8 @@ int api_set_option(const char *name, double v) {
     else if (k == "block_factor") g_opt.block_factor = (int)v;
     else if (k == "pin_last") g_opt.pin_last = (int)v;
     else if (k == "fused_panel") g_opt.fused_panel = (int)v;
+    else if (k == "batch_extend") g_opt.batch_extend = (int)v;
+    else if (k == "extend_tail_fronts") g_opt.extend_tail_fronts = (int)v;
     else return -1;
     return 0;
 }

@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak; HBM peak from MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+PMC_TAG = "r02"              # profiles/<tag>_pmc_*.json written by tools/profile_round.sh <tag>
 FLOP_KERNELS = {"k_front_small", "k_front_medium", "k_syrk_big", "k_panel_big", "k_diag_big"}
 
 
@@ -47,22 +48,54 @@ def kernel_profile(lib, p):
     return [dict(name=names[k].decode(), ms=ms[k], calls=calls[k], flops=fl[k], bytes=by[k]) for k in range(n)]
 
 
+def source_hash():
+    """sha256[:16] of the kernel + host runtime sources: profiles/*_pmc_*.json carry the hash they were collected with"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip.h", "solver.hip.cpp"):
+        h.update(open(os.path.join(ROOT, "aprilsam_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(name):
+    """committed PMC summary (separate rocprofv3 --pmc passes, tools/profile_round.sh) -- refused when it was collected
+    with other kernel sources than the ones this bench is running (stale counters are worse than none)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None, "not collected"
+    if d.get("source_hash") != source_hash():
+        return None, f"stale: collected for sources {d.get('source_hash')}, running {source_hash()}"
+    return d, f"profiles/{name}"
+
+
+def hbm_rooflines(prof, iters):
+    """roofline entries of the bandwidth-bound kernels from an instrumented pass of `iters` iterations: algorithmic bytes
+    (SURVEY.md section 8(d) conventions, aprilsam_amd_kernel_profile) / HIP-event time"""
+    out = []
+    for name in ("k_linearize", "k_assemble_big", "k_backsolve"):
+        k = next((q for q in prof if q["name"] == name), None)
+        if not k or k["ms"] <= 0 or k["bytes"] <= 0:
+            continue
+        ach = k["bytes"] / (k["ms"] / iters * 1e-3) / 1e9
+        out.append(dict(kernel=name, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                        algorithmic_bytes_per_step=k["bytes"], kernel_ms_per_step=k["ms"] / iters, launches_per_step=k["calls"] / iters))
+    return out
+
+
 def big_front_roofline(prof, iters):
     """roofline entry of the wide-supernode path (k_syrk_big: v_mfma_f64_16x16x4_f64) from an instrumented pass of `iters` iterations"""
     k = next((q for q in prof if q["name"] == "k_syrk_big"), None)
     if not k or k["ms"] <= 0 or k["flops"] <= 0:
         return None
     ach = k["flops"] / (k["ms"] / iters * 1e-3) / 1e12
-    mfma = None
-    try:
-        m = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")))["kernels"]["k_syrk_big"]
-        mfma = m["mfma_busy_over_cu_busy"]
-    except Exception:
-        pass
+    pmc, src = load_pmc(PMC_TAG + "_pmc_mfma.json")
+    mfma = pmc["kernels"].get("k_syrk_big", {}).get("mfma_busy_over_cu_busy") if pmc else None
     return dict(kernel="k_syrk_big", bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS,
                 kernel_ms_per_step=k["ms"] / iters, launches_per_step=k["calls"] / iters,
-                algorithmic_flops_per_step=k["flops"], mfma_pipe_busy_fraction_100k_profile=mfma,
-                note="flops = sum c_j^2 of the fronts on the multi-workgroup path; measured FP64 MFMA ceiling on this box 34-46 TFLOP/s (tools/ubench/mfma_f64.hip)")
+                algorithmic_flops_per_step=k["flops"], mfma_pipe_busy_fraction_100k_profile=mfma, mfma_counter_source=src,
+                note="flops = sum c_j^2 of the fronts on the multi-workgroup path; measured FP64 MFMA ceiling on this box 34-46 TFLOP/s "
+                     "(tools/ubench/mfma_f64.hip, output in profiles/)")
 
 
 def timed_steps(lib, g, p, K, sync_all, barrier):
@@ -195,7 +228,7 @@ def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iter
         res.update(parallelism="single GPU", kernels_ms_per_step={k["name"]: round(k["ms"] / 2, 3) for k in lp},
                    nnz_L=st["nnz_L"], sum_cj2=st["flops_factor"], fronts=st["n_fronts"], levels=st["n_levels"],
                    max_front_rows=st["max_front_rows"], factor_tflops=st["flops_factor"] / (1e-3 * fac_ms) / 1e12,
-                   roofline=big_front_roofline(lp, 2))
+                   roofline=big_front_roofline(lp, 2), roofline_hbm=hbm_rooflines(lp, 2))
         lib.dll.aprilsam_amd_resident_end(g.ptr, p.ptr)
     else:
         from aprilsam_amd.shard import ShardedSolver
@@ -295,12 +328,13 @@ def main():
     # this same workload): (2 x FETCH_SIZE + WRITE_SIZE) KB — the x2 on the read side is the gfx950 correction of
     # MI355X_MICROARCH.md section HBM (calibrated there for wide coalesced reads; our 8-byte loads are uncalibrated)
     traffic = None
+    pmc, pmc_src = load_pmc(PMC_TAG + "_pmc_hbm.json")
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))["counters"]
-        traffic = 1024.0 * (2.0 * pmc["FETCH_SIZE"][dom["name"]]["kb_per_dispatch"] + pmc["WRITE_SIZE"][dom["name"]]["kb_per_dispatch"])
+        cn = pmc["counters"]
+        traffic = 1024.0 * (2.0 * cn["FETCH_SIZE"][dom["name"]]["kb_per_dispatch"] + cn["WRITE_SIZE"][dom["name"]]["kb_per_dispatch"])
     except Exception:
         pass
-    roof.update(kernel=dom["name"], traffic=traffic, traffic_source="profiles/r01_pmc_hbm.json (bytes per launch)" if traffic else None,
+    roof.update(kernel=dom["name"], traffic=traffic, traffic_source=(pmc_src + " (bytes per launch)") if traffic else pmc_src,
                 avg_launch_us=1e3 * dom["ms"] / max(1, dom["calls"]),
                 launches_per_step=dom["launches_per_iter"], kernel_ms_per_step=dom["ms_per_iter"],
                 algorithmic_work_per_step=dom["flops"] if dom["name"] in FLOP_KERNELS else dom["bytes"],
@@ -322,6 +356,7 @@ def main():
         "roofline": roof,
         "kernels_ms_per_step": {k["name"]: round(k["ms_per_iter"], 5) for k in prof},
         "kernel_launches_per_step": {k["name"]: k["launches_per_iter"] for k in prof},
+        "source_hash": source_hash(),
     }
     if rank == 0 and world == 1 and not a.no_lattice:
         try:
@@ -348,7 +383,7 @@ def main():
                 "nnz_L": ls["nnz_L"], "sum_cj2": ls["flops_factor"], "fronts": ls["n_fronts"], "levels": ls["n_levels"],
                 "kernels_ms_per_step": {k["name"]: round(k["ms"] / 3, 4) for k in lp},
                 "factor_tflops": ls["flops_factor"] / (1e-3 * sum(k["ms"] / 3 for k in lp if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big"))) / 1e12,
-                "roofline": big_front_roofline(lp, 3),
+                "roofline": big_front_roofline(lp, 3), "roofline_hbm": hbm_rooflines(lp, 3),
             }
             lib.dll.aprilsam_amd_resident_end(g.ptr, p.ptr)
             p.destroy(); g.destroy()
@@ -386,6 +421,30 @@ def main():
             out["api"] = api_calls(lib, arrays)
         except Exception as e:
             out["api"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not a.no_inc:
+        # the cold call in its natural habitat: the reference demo's --batch_update_only mode (examples/aprilsam_demo.c:224-228),
+        # one april_graph_cholesky per new pose on a growing graph -- every call sees a new topology
+        try:
+            from aprilsam_amd import harness
+            from tests.support.oracle_binding import REFLIB
+            npos = 1200
+            r = harness.run_demo(lib, datasets.m3500_arrays(), batch_update_only=True, max_poses=npos)
+            ms = r["ms"][1:]
+            gb = {"workload": f"M3500 demo --batch_update_only, first {npos} poses: one april_graph_cholesky call per new pose through the reference API",
+                  "total_ms": float(ms.sum()), "mean_ms": float(ms.mean()), "median_ms": float(np.median(ms)), "p99_ms": float(np.percentile(ms, 99)),
+                  "final_chi2": float(r["chi2"][-1]),
+                  "note": "batch_extend: the plan is kept while the graph only grows (appended poses become tail fronts, every front is "
+                          "re-factorised); full re-plan every 8 tail fronts"}
+            if os.path.exists(REFLIB) and not a.no_cpu_baseline:
+                rr = harness.run_demo(host.SolverLib(REFLIB), datasets.m3500_arrays(), batch_update_only=True, max_poses=npos)
+                rms = rr["ms"][1:]
+                gb["reference_cpu_same_host"] = {"total_ms": float(rms.sum()), "mean_ms": float(rms.mean()), "median_ms": float(np.median(rms)), "cores": 1,
+                                                 "final_chi2": float(rr["chi2"][-1])}
+                gb["speedup_total_vs_reference"] = float(rms.sum() / ms.sum())
+                gb["chi2_max_relerr_vs_reference"] = float(np.max(np.abs(r["chi2"] - rr["chi2"]) / np.maximum(rr["chi2"], 1e-9)))
+            out["m3500_batch_update_only"] = gb
+        except Exception as e:
+            out["m3500_batch_update_only"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(arrays)
         out["cpu_baseline"]["host"] = f"{os.cpu_count()} logical cores visible; reference is single-threaded"

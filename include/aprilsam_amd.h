@@ -239,6 +239,10 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *   "small_threads", "tp_threads"  workgroup size of the single-workgroup front kernel (256 / 512 / 1024) on
  *                       latency-bound levels (default 1024) and on throughput levels (default 512)
  *   "syrk128_rows"      trailing updates at least this tall use the LDS-staged 128x128 MFMA kernel (default off)
+ *   "batch_extend"      1 (default): april_graph_cholesky on a graph that only GREW since the last plan keeps the plan -- the
+ *                       appended poses become tail fronts, every front is re-factorised (batch semantics) -- instead of a new
+ *                       ordering + symbolic analysis per call; "extend_tail_fronts" (default 8) tail fronts of 24 poses later,
+ *                       or when the topology stops changing, a full re-plan follows.  0 = re-plan on every topology change
  *   "pin_last"          k > 0: the k newest poses are kept out of the nested dissection and form the root front ("recent
  *                       poses last", cf. aprilsam.c:1021-1098); default 0, measured effect in profiles/r02_inc_hist.json
  *   "inc_fast"          0 = every incremental step re-plans (default 1: frozen base plan + dirty root paths) */

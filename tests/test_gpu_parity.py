@@ -386,6 +386,26 @@ def _random_growth(lib, rng_seed, steps, nthreshold, old_old=False):
     return trace
 
 
+@pytest.mark.parametrize("extend", [1, 0])
+def test_batch_calls_on_a_growing_graph_match_the_live_reference(lib, reflib, extend):
+    """the reference demo's --batch_update_only mode (examples/aprilsam_demo.c:224-228): one april_graph_cholesky per new
+    pose on a graph that grows by a pose and its factors each time.  With batch_extend (default) the library keeps the
+    plan and appends tail fronts instead of re-planning per call; both ways every step's chi^2 and the final states must
+    equal the unmodified reference's."""
+    from aprilsam_amd import harness
+    n = 420
+    lib.set_option("batch_extend", extend)
+    try:
+        ours = harness.run_demo(lib, datasets.m3500_arrays(), batch_update_only=True, max_poses=n)
+    finally:
+        lib.set_option("batch_extend", 1)
+    ref = harness.run_demo(reflib, datasets.m3500_arrays(), batch_update_only=True, max_poses=n)
+    assert np.max(np.abs(ours["chi2"] - ref["chi2"]) / np.maximum(ref["chi2"], 1e-6)) < 1e-6
+    assert np.max(np.abs(ours["final_states"] - ref["final_states"])) < 1e-6
+    if extend:      # ... and it is what makes the cold call cheap: far less time than re-planning every step
+        assert ours["ms"][50:].mean() < 2.0
+
+
 def test_factors_edited_in_place_are_seen_by_the_next_call(lib, reflib):
     """the reference re-reads every factor object on every call (aprilsam.c:152-190, april_graph.c:79-98): a caller may
     edit z / W of an existing factor in place, or replace a factor object, between two calls.  Default options

@@ -9,6 +9,9 @@ import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 src, tag = sys.argv[1], sys.argv[2]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+SRC_HASH = bench.source_hash()
 dst = os.path.join(src, "summary"); os.makedirs(dst, exist_ok=True)
 
 
@@ -34,7 +37,8 @@ def counters(sub):
     return {c: {k: {"dispatches": v[0], "total": round(v[1], 1), "per_dispatch": round(v[1] / v[0], 2)} for k, v in ks.items()} for c, ks in acc.items()}
 
 
-for sub, out in (("stats", f"{tag}_kernel_stats.csv"), ("stats_lattice", f"{tag}_kernel_stats_lattice.csv")):
+for sub, out in (("stats", f"{tag}_kernel_stats.csv"), ("stats_lattice", f"{tag}_kernel_stats_lattice.csv"), ("stats_lattice1m", f"{tag}_kernel_stats_lattice1m.csv"),
+                 ("stats_inc", f"{tag}_kernel_stats_inc_demo.csv")):
     f = find(sub, "*kernel_stats.csv")
     if f:
         shutil.copy(f, os.path.join(dst, out)); print("wrote", out)
@@ -44,22 +48,30 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     if r and c in r:
         hbm[c] = {k: {"dispatches": v["dispatches"], "total_kb": v["total"], "kb_per_dispatch": v["per_dispatch"]} for k, v in r[c].items()}
 if hbm:
-    json.dump({"command": "APRILSAM_AMD_USE_GRAPH=0 rocprofv3 --pmc <COUNTER> --output-format csv -- python bench.py --steps 10 --warmup 2 --no-lattice "
+    json.dump({"source_hash": SRC_HASH, "command": "APRILSAM_AMD_USE_GRAPH=0 rocprofv3 --pmc <COUNTER> --output-format csv -- python bench.py --steps 10 --warmup 2 --no-lattice "
                           "--no-inc --no-cpu-baseline (one pass per counter, hipGraph replay off)",
                "unit": "KB as reported by rocprofv3; MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 - "
                        "values are RAW, bench.py applies the x2 to the read side", "counters": hbm},
               open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
     print("wrote", f"{tag}_pmc_hbm.json")
-m = counters("pmc_mfma")
-if m:
+for sub, label, out in (("pmc_mfma", "python tools/lattice_big.py 316 2   (100k-pose lattice, config 4", f"{tag}_pmc_mfma.json"),
+                        ("pmc_mfma1m", "python tools/lattice_big.py 1000 1   (1M-pose lattice, config 5", f"{tag}_pmc_mfma_lattice1m.json")):
+    m = counters(sub)
+    if not m:
+        continue
     per = {}
     for k in set().union(*[set(v) for v in m.values()]):
         g = lambda c: m.get(c, {}).get(k, {}).get("total", 0.0)
         busy, cu, ops = g("SQ_VALU_MFMA_BUSY_CYCLES"), g("SQ_BUSY_CU_CYCLES"), g("SQ_INSTS_VALU_MFMA_MOPS_F64")
         per[k] = {"dispatches": m[next(iter(m))].get(k, {}).get("dispatches", 0), "SQ_VALU_MFMA_BUSY_CYCLES": busy, "SQ_BUSY_CU_CYCLES": cu,
                   "SQ_INSTS_VALU_MFMA_MOPS_F64": ops, "GRBM_GUI_ACTIVE": g("GRBM_GUI_ACTIVE"),
-                  "mfma_busy_over_cu_busy": round(busy / cu, 4) if cu else None}
-    json.dump({"command": "APRILSAM_AMD_USE_GRAPH=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE "
-                          "-- python tools/lattice_big.py 316 2   (100k-pose lattice, config 4; sums over all dispatches of the run)",
-               "kernels": per}, open(os.path.join(dst, f"{tag}_pmc_mfma.json"), "w"), indent=1)
-    print("wrote", f"{tag}_pmc_mfma.json")
+                  "mfma_busy_over_cu_busy": round(busy / cu, 4) if cu else None,
+                  "cus_busy_on_average": round(cu / g("GRBM_GUI_ACTIVE"), 2) if g("GRBM_GUI_ACTIVE") else None}
+    json.dump({"source_hash": SRC_HASH,
+               "command": "APRILSAM_AMD_USE_GRAPH=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE "
+                          "-- " + label + "; sums over all dispatches of the run)",
+               "kernels": per}, open(os.path.join(dst, out), "w"), indent=1)
+    print("wrote", out)
+for f in ("ubench_mfma_f64.txt", "ubench_valu_lat.txt"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}")); print("wrote", f"{tag}_{f}")

@@ -4,7 +4,7 @@
 # Outputs under gpurun_out/prof_<tag>/ ; tools/pmc_aggregate.py turns them into the files kept in profiles/.
 # Counter passes are separate runs (one --pmc set each, no trace domains besides the kernel trace), without hipGraph
 # replay (counter collection over graph replays does not terminate on ROCm 7.2) and each under its own timeout.
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -20,6 +20,14 @@ done
 # MFMA utilisation of the wide-supernode path: 100k lattice (config 4), counters per dispatch
 APRILSAM_AMD_USE_GRAPH=0 timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- $LAT > $OUT/pmc_mfma.log 2>&1
 APRILSAM_AMD_USE_GRAPH=0 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lattice -- $LAT > $OUT/stats_lattice.log 2>&1
+# config 5 on one GPU (1M poses): kernel stats + MFMA counters of the wide-supernode path
+APRILSAM_AMD_USE_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lattice1m -- python $ROOT/tools/lattice_big.py 1000 1 > $OUT/stats_lattice1m.log 2>&1
+APRILSAM_AMD_USE_GRAPH=0 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma1m -- python $ROOT/tools/lattice_big.py 1000 1 > $OUT/pmc_mfma1m.log 2>&1
+# config 3: the incremental demo (first 1500 poses)
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_inc -- python $ROOT/tools/inc_demo.py 1500 > $OUT/stats_inc.log 2>&1
+# instruction-rate micro-benchmarks the roofline discussion quotes
+timeout 60 $ROOT/tools/ubench/mfma_f64 > $OUT/ubench_mfma_f64.txt 2>&1
+timeout 60 $ROOT/tools/ubench/valu_lat > $OUT/ubench_valu_lat.txt 2>&1
 cd $ROOT
 python tools/pmc_aggregate.py $OUT $TAG > $OUT/aggregate.log 2>&1
 tail -5 $OUT/aggregate.log
