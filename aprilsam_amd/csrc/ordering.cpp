@@ -26,10 +26,11 @@ namespace {
 struct HopcroftKarp {
     int nl = 0, nr = 0;
     std::vector<int> ptr, idx;        // left -> right adjacency
-    std::vector<int> ml, mr, dist, it;
+    std::vector<int> ml, mr, dist, it, q;
+    std::vector<char> zl, zr;
 
     bool bfs() {
-        std::vector<int> q; q.reserve(nl);
+        q.clear();
         bool found = false;
         for (int u = 0; u < nl; u++) { if (ml[u] < 0) { dist[u] = 0; q.push_back(u); } else dist[u] = -1; }
         for (size_t h = 0; h < q.size(); h++) {
@@ -59,8 +60,8 @@ struct HopcroftKarp {
     }
     // minimum vertex cover (Koenig): inL[u] / inR[v] = 1 if in cover
     void cover(std::vector<char> &inL, std::vector<char> &inR) {
-        std::vector<char> zl(nl, 0), zr(nr, 0);
-        std::vector<int> q;
+        zl.assign(nl, 0); zr.assign(nr, 0);
+        q.clear();
         for (int u = 0; u < nl; u++) if (ml[u] < 0) { zl[u] = 1; q.push_back(u); }
         for (size_t h = 0; h < q.size(); h++) {
             int u = q[h];
@@ -132,6 +133,8 @@ struct Dissector {
     Shared &sh;
     int *dist, *loc; char *side;
     Dinic dinic;                // scratch of refine_band
+    HopcroftKarp hk_;           // scratch of cut_to_separator (buffers reused across the hundreds of calls of one plan)
+    std::vector<int> B0_, B1_, band_; std::vector<char> inL_, inR_; std::vector<std::pair<double, int>> pr_;
 
     Dissector(int N_, const std::vector<int> &ap_, const std::vector<int> &ai_, const double *xy_, int leaf_, NDTree &t, Shared &sh_)
         : N(N_), ap(ap_), ai(ai_), xy(xy_), leaf(leaf_), tree(t), sh(sh_), dist(sh_.dist.data()), loc(sh_.loc.data()), side(sh_.side.data()) {}
@@ -163,22 +166,22 @@ struct Dissector {
 
     // side[v] in {0,1} given for all v of comp: edge cut -> minimum vertex separator
     void cut_to_separator(const std::vector<int> &comp, int L, Split &out) {
-        std::vector<int> B0, B1;
+        std::vector<int> &B0 = B0_, &B1 = B1_; B0.clear(); B1.clear();
         for (int v : comp) {
             bool b = false;
             for (int e = ap[v]; e < ap[v + 1] && !b; e++) { int w = ai[e]; b = (lab(w) == L && side[w] != side[v]); }
             if (b) { if (side[v] == 0) { loc[v] = (int)B0.size(); B0.push_back(v); } else { loc[v] = (int)B1.size(); B1.push_back(v); } }
         }
         if (B0.empty() || B1.empty()) { out.ok = false; return; }
-        HopcroftKarp hk; hk.nl = (int)B0.size(); hk.nr = (int)B1.size();
-        hk.ptr.assign(hk.nl + 1, 0);
+        HopcroftKarp &hk = hk_; hk.nl = (int)B0.size(); hk.nr = (int)B1.size();
+        hk.ptr.assign(hk.nl + 1, 0); hk.idx.clear();
         for (int i = 0; i < hk.nl; i++) {
             int v = B0[i];
             for (int e = ap[v]; e < ap[v + 1]; e++) { int w = ai[e]; if (lab(w) == L && side[w] == 1) hk.idx.push_back(loc[w]); }
             hk.ptr[i + 1] = (int)hk.idx.size();
         }
         hk.run();
-        std::vector<char> inL, inR; hk.cover(inL, inR);
+        std::vector<char> &inL = inL_, &inR = inR_; hk.cover(inL, inR);
         // mark separator members with loc = -2 (loc is reset to -1 below)
         for (int i = 0; i < hk.nl; i++) loc[B0[i]] = inL[i] ? -2 : -1;
         for (int i = 0; i < hk.nr; i++) loc[B1[i]] = inR[i] ? -2 : -1;
@@ -216,7 +219,7 @@ struct Dissector {
         for (int v : sp.P0) side[v] = 0;
         for (int v : sp.P1) side[v] = 1;
         for (int v : sp.S) side[v] = 2;
-        std::vector<int> band;                       // BFS from the separator, depth <= width
+        std::vector<int> &band = band_; band.clear();      // BFS from the separator, depth <= width
         for (int v : sp.S) { dist[v] = 0; band.push_back(v); }
         for (size_t h = 0; h < band.size(); h++) {
             int u = band[h];
@@ -293,7 +296,7 @@ struct Dissector {
         // principal direction of the 2x2 covariance
         double th = 0.5 * std::atan2(2 * sxy, sxx - syy) + rot;
         double ux = std::cos(th), uy = std::sin(th);
-        std::vector<std::pair<double, int>> pr(n);
+        std::vector<std::pair<double, int>> &pr = pr_; pr.resize(n);
         for (size_t i = 0; i < n; i++) { int v = comp[i]; pr[i] = { (xy[2 * v] - mx) * ux + (xy[2 * v + 1] - my) * uy, v }; }
         std::nth_element(pr.begin(), pr.begin() + n / 2, pr.end());
         for (size_t i = 0; i < n; i++) side[pr[i].second] = i < n / 2 ? 0 : 1;

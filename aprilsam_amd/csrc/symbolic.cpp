@@ -161,9 +161,24 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
             rd.push_back({ t, lb, 0, 2 * f + 1 });
         }
     }
-    auto cmp = [](const Dest &x, const Dest &y) { return std::tie(x.front, x.col, x.row, x.src) < std::tie(y.front, y.col, y.row, y.src); };
-    std::sort(bd.begin(), bd.end(), cmp);
-    std::sort(rd.begin(), rd.end(), cmp);
+    // order (front, col, row, src): counting sort by front, then a sort of 64-bit packed keys inside every (small) bucket --
+    // several times faster than one comparison sort over all 5 F records, and planning sits on the cold-call path
+    auto sort_dests = [&](std::vector<Dest> &v) {
+        std::vector<int> ptr(nT + 1, 0);
+        for (const Dest &d : v) ptr[d.front + 1]++;
+        for (int t = 0; t < nT; t++) ptr[t + 1] += ptr[t];
+        std::vector<unsigned long long> key(v.size());
+        { std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+          for (const Dest &d : v) key[fill[d.front]++] = ((unsigned long long)(unsigned)d.col << 44) | ((unsigned long long)(unsigned)(d.row + 1) << 26) | (unsigned)d.src; }
+        for (int t = 0; t < nT; t++) {
+            std::sort(key.begin() + ptr[t], key.begin() + ptr[t + 1]);
+            for (int i = ptr[t]; i < ptr[t + 1]; i++) v[i] = { t, (int)(key[i] >> 44), (int)((key[i] >> 26) & 0x3ffff) - 1, (int)(key[i] & 0x3ffffff) };
+        }
+    };
+    static_assert(sizeof(unsigned long long) == 8, "packed sort keys");
+    if ((size_t)3 * F >= (1u << 26)) { fprintf(stderr, "aprilsam_amd: too many factors for the packed sort keys\n"); abort(); }
+    sort_dests(bd);
+    sort_dests(rd);
     auto compress = [&](const std::vector<Dest> &v, std::vector<int> &front_ptr, std::vector<int> &row, std::vector<int> &col,
                         std::vector<int> &src_ptr, std::vector<int> &src) {
         front_ptr.assign(nT + 1, 0); row.clear(); col.clear(); src_ptr.clear(); src.clear();
@@ -186,7 +201,18 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
         std::vector<U> all; all.reserve(bd.size() + rd.size());
         for (const Dest &d : bd) all.push_back({ d.front, d.col, d.row, d.src, 0 });
         for (const Dest &d : rd) all.push_back({ d.front, d.col, -1, d.src, 1 });     // brow -1 = the rhs row
-        std::sort(all.begin(), all.end(), [](const U &x, const U &y) { return std::tie(x.front, x.col, x.row, x.src) < std::tie(y.front, y.col, y.row, y.src); });
+        {   // same order as above with brow = -1 first inside a column: merge of two sorted runs per front = one sort of packed keys per bucket
+            std::vector<int> ptr(nT + 1, 0);
+            for (const U &u : all) ptr[u.front + 1]++;
+            for (int t = 0; t < nT; t++) ptr[t + 1] += ptr[t];
+            std::vector<unsigned long long> key(all.size());
+            { std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+              for (const U &u : all) key[fill[u.front]++] = ((unsigned long long)(unsigned)u.col << 45) | ((unsigned long long)(unsigned)(u.row + 1) << 27) | ((unsigned long long)(unsigned)u.src << 1) | (unsigned)u.rhs; }
+            for (int t = 0; t < nT; t++) {
+                std::sort(key.begin() + ptr[t], key.begin() + ptr[t + 1]);
+                for (int i = ptr[t]; i < ptr[t + 1]; i++) all[i] = { t, (int)(key[i] >> 45), (int)((key[i] >> 27) & 0x3ffff) - 1, (int)((key[i] >> 1) & 0x3ffffff), (int)(key[i] & 1) };
+            }
+        }
         P.dest_front_ptr.assign(nT + 1, 0); P.dest.clear();
         P.slot_blk.assign((size_t)3 * F, -1); P.slot_rhs.assign((size_t)2 * F, -1);
         for (size_t i = 0; i < all.size(); i++) {
