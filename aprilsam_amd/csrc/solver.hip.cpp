@@ -1369,11 +1369,16 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         // flag in pinned mirrors.  No copy-engine call on the path.
         run_numeric(c, gp, timing, false, true);
     }
+    // while the GPU works: a param that is used incrementally needs the reference's elimination tree of THIS batch step for
+    // its next april_graph_cholesky_inc (refmodel.cpp: the reference's own min-degree order, ~1 ms of integer work on M3500)
+    bool model_ready = false;
+    if (c.want_inc && gp.host_idx.empty()) { c.model.batch(N, F, gp.h_fa.p, gp.h_fb.p); model_ready = true; }
     HIPCHECK(hipStreamSynchronize(gp.stream));
     const double t4 = now_ms();
     c.st.not_spd = c.h_bad.p[0] != 0;
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
     if (c.st.not_spd) {
+        c.model.valid = false;
         static bool warned = false;
         if (!warned) { fprintf(stderr, "aprilsam_amd: information matrix not positive definite; node states left untouched\n"); warned = true; }
     } else {
@@ -1394,7 +1399,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
         param->nreordering = N;
         param->factor_num = F;
-        c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = false;
+        c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = model_ready;
         if (!hybrid) inc_prepare(c);                     // (an extended plan keeps its base + tail bookkeeping)
         c.inc_F = F; c.inc_N = N;
         record_unary_points(gp, 0, F, gp.h_state.p);         // the linearisation point of this call
@@ -1948,7 +1953,7 @@ void shard_map(const Plan &P, int world, std::vector<int> &owner, std::vector<ch
     {   // several roots (disconnected graph): spread them like children of a virtual root
         std::vector<int> roots; for (int t = 0; t < P.nF; t++) if (P.f_parent[t] < 0) roots.push_back(t);
         std::sort(roots.begin(), roots.end(), [&](int a, int b) { return work[a] != work[b] ? work[a] > work[b] : a < b; });
-        for (size_t i = 0; i < roots.size(); i++) { lo[roots[i]] = (int)(i % world) * 0; hi[roots[i]] = world; }
+        for (size_t i = 0; i < roots.size(); i++) { lo[roots[i]] = 0; hi[roots[i]] = world; }       // (every root spans all ranks)
     }
     for (int t = P.nF - 1; t >= 0; t--) {
         S.owner[t] = lo[t]; S.top[t] = (hi[t] - lo[t]) > 1;
@@ -2035,7 +2040,7 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
     // ---- exchange lists of this rank ------------------------------------------------------------------------------
     S.up.assign(P.nLevels, {}); S.down.assign(P.nLevels, {});
     long long send_max = 1, recv_max = 1;
-    for (size_t i = 0; i + 5 < S.xfer.size() + 1 && i < S.xfer.size(); i += 6) {
+    for (size_t i = 0; i + 6 <= S.xfer.size(); i += 6) {
         const int lev = (int)S.xfer[i], front = (int)S.xfer[i + 1], src = (int)S.xfer[i + 2], dst = (int)S.xfer[i + 3];
         S.up[lev].push_back({ front, src, dst, S.xfer[i + 5], 0 });
     }

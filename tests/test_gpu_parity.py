@@ -81,11 +81,16 @@ def test_tutorial_batch_mode_matches_reference_golden(lib):
 
 @pytest.mark.parametrize("opts", [dict(small_lds_kb=0), dict(small_lds_kb=48), dict(small_lds_kb=156), dict(panel_mode=0, small_lds_kb=64),
                                   dict(small_threads=256), dict(small_threads=512), dict(tp_fronts=1, tp_lds_kb=8), dict(lookahead=1, small_lds_kb=0), dict(lookahead=1, small_lds_kb=0, use_graph=0), dict(syrk128_rows=64, small_lds_kb=0),
-                                  dict(leaf_nodes=4), dict(leaf_nodes=40), dict(use_graph=0), dict(device_timing=1)])
+                                  dict(leaf_nodes=4), dict(leaf_nodes=40), dict(use_graph=0), dict(device_timing=1),
+                                  dict(block_factor=0), dict(block_factor=0, panel_mode=0, small_lds_kb=64), dict(fused_panel=0, small_lds_kb=0),
+                                  dict(fused_panel=0, small_lds_kb=0, lookahead=1), dict(pin_last=12), dict(trust_factor_cache=1)])
 def test_every_kernel_path_agrees_with_oracle(lib, oracle, opts):
-    """force the multi-workgroup big-front path (with and without the LDS-staged MFMA tile kernel), small LDS budgets
-    (more panel-mode and big fronts), panel mode off, other workgroup sizes and leaf sizes, no hipGraph: same answers"""
-    defaults = dict(small_lds_kb=156, panel_mode=1, small_threads=1024, tp_fronts=1000, tp_lds_kb=64, lookahead=0, syrk128_rows=1 << 30, leaf_nodes=16, use_graph=1, device_timing=0)
+    """force the multi-workgroup big-front path (with and without the LDS-staged MFMA tile kernel, with the fused and the
+    two-kernel panel step), small LDS budgets (more panel-mode and big fronts), panel mode off, the per-pivot elimination
+    instead of the in-register 16-column chain, other workgroup sizes and leaf sizes, the newest poses pinned into the root
+    front, no hipGraph: same answers"""
+    defaults = dict(small_lds_kb=156, panel_mode=1, small_threads=1024, tp_fronts=1000, tp_lds_kb=64, lookahead=0, syrk128_rows=1 << 30, leaf_nodes=16, use_graph=1, device_timing=0,
+                    block_factor=1, fused_panel=1, pin_last=0, trust_factor_cache=0)
     arr = datasets.random_pose_graph(700, 600, 21)
     oc, ost = oracle.iterate(arr, 2)
     try:
