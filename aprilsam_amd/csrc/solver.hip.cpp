@@ -1845,6 +1845,7 @@ int debug_front_times(const april_graph_cholesky_param_t *param, long long *out,
 // exchange) or host callbacks (the caller moves pinned host buffers with whatever it has: the tests use gloo, a C host
 // could use MPI); the schedule above them is the same.
 struct Transport {
+    bool failed = false; std::string error;       // a communication error ends the sharded run with a return code, not the process
     virtual ~Transport() {}
     virtual void group_begin() {}
     virtual void group_end() {}
@@ -1881,21 +1882,20 @@ struct RcclApi {
     }
 };
 static RcclApi g_rccl;
-#define RCCLCHECK(expr)                                                                                     \
-    do {                                                                                                    \
-        ncclResult_t r_ = (expr);                                                                           \
-        if (r_ != ncclSuccess) { fprintf(stderr, "aprilsam_amd: FATAL: %s failed: %s\n", #expr, g_rccl.GetErrorString(r_)); fflush(stderr); abort(); } \
-    } while (0)
-
 struct RcclTransport : Transport {
     ncclComm_t comm = nullptr;
     ~RcclTransport() override { if (comm) (void)g_rccl.CommDestroy(comm); }
-    void group_begin() override { RCCLCHECK(g_rccl.GroupStart()); }
-    void group_end() override { RCCLCHECK(g_rccl.GroupEnd()); }
-    void send(const double *dev, long long n, int dst, hipStream_t s) override { RCCLCHECK(g_rccl.Send(dev, (size_t)n, ncclFloat64, dst, comm, s)); }
-    void recv(double *dev, long long n, int src, hipStream_t s) override { RCCLCHECK(g_rccl.Recv(dev, (size_t)n, ncclFloat64, src, comm, s)); }
-    void bcast(double *dev, long long n, int root, hipStream_t s) override { RCCLCHECK(g_rccl.Broadcast(dev, dev, (size_t)n, ncclFloat64, root, comm, s)); }
-    void allreduce_sum(double *dev, long long n, hipStream_t s) override { RCCLCHECK(g_rccl.AllReduce(dev, dev, (size_t)n, ncclFloat64, ncclSum, comm, s)); }
+    void chk(ncclResult_t r, const char *what) {
+        if (r == ncclSuccess || failed) return;
+        failed = true; error = std::string(what) + ": " + g_rccl.GetErrorString(r);
+        fprintf(stderr, "aprilsam_amd: RCCL error in %s\n", error.c_str());
+    }
+    void group_begin() override { if (!failed) chk(g_rccl.GroupStart(), "ncclGroupStart"); }
+    void group_end() override { if (!failed) chk(g_rccl.GroupEnd(), "ncclGroupEnd"); }
+    void send(const double *dev, long long n, int dst, hipStream_t s) override { if (!failed) chk(g_rccl.Send(dev, (size_t)n, ncclFloat64, dst, comm, s), "ncclSend"); }
+    void recv(double *dev, long long n, int src, hipStream_t s) override { if (!failed) chk(g_rccl.Recv(dev, (size_t)n, ncclFloat64, src, comm, s), "ncclRecv"); }
+    void bcast(double *dev, long long n, int root, hipStream_t s) override { if (!failed) chk(g_rccl.Broadcast(dev, dev, (size_t)n, ncclFloat64, root, comm, s), "ncclBroadcast"); }
+    void allreduce_sum(double *dev, long long n, hipStream_t s) override { if (!failed) chk(g_rccl.AllReduce(dev, dev, (size_t)n, ncclFloat64, ncclSum, comm, s), "ncclAllReduce"); }
     const char *name() const override { return "rccl"; }
 };
 
@@ -1904,11 +1904,15 @@ struct HostTransport : Transport {
     HBuf<double> stage;
     void down(const double *dev, long long n, hipStream_t s) { stage.need((size_t)n); HIPCHECK(hipMemcpyAsync(stage.p, dev, (size_t)n * 8, hipMemcpyDeviceToHost, s)); HIPCHECK(hipStreamSynchronize(s)); }
     void up(double *dev, long long n, hipStream_t s) { HIPCHECK(hipMemcpyAsync(dev, stage.p, (size_t)n * 8, hipMemcpyHostToDevice, s)); HIPCHECK(hipStreamSynchronize(s)); }
-    static void chk(int rc, const char *what) { if (rc != 0) { fprintf(stderr, "aprilsam_amd: FATAL: host communication callback %s returned %d\n", what, rc); fflush(stderr); abort(); } }
-    void send(const double *dev, long long n, int dst, hipStream_t s) override { down(dev, n, s); chk(cb.send(cb.user, stage.p, n, dst), "send"); }
-    void recv(double *dev, long long n, int src, hipStream_t s) override { stage.need((size_t)n); chk(cb.recv(cb.user, stage.p, n, src), "recv"); up(dev, n, s); }
-    void bcast(double *dev, long long n, int root, hipStream_t s) override { down(dev, n, s); chk(cb.bcast(cb.user, stage.p, n, root), "bcast"); up(dev, n, s); }
-    void allreduce_sum(double *dev, long long n, hipStream_t s) override { down(dev, n, s); chk(cb.allreduce_sum(cb.user, stage.p, n), "allreduce_sum"); up(dev, n, s); }
+    void chk(int rc, const char *what) {
+        if (rc == 0 || failed) return;
+        failed = true; error = std::string("host communication callback ") + what + " returned " + std::to_string(rc);
+        fprintf(stderr, "aprilsam_amd: %s\n", error.c_str());
+    }
+    void send(const double *dev, long long n, int dst, hipStream_t s) override { if (failed) return; down(dev, n, s); chk(cb.send(cb.user, stage.p, n, dst), "send"); }
+    void recv(double *dev, long long n, int src, hipStream_t s) override { if (failed) return; stage.need((size_t)n); chk(cb.recv(cb.user, stage.p, n, src), "recv"); up(dev, n, s); }
+    void bcast(double *dev, long long n, int root, hipStream_t s) override { if (failed) return; down(dev, n, s); chk(cb.bcast(cb.user, stage.p, n, root), "bcast"); up(dev, n, s); }
+    void allreduce_sum(double *dev, long long n, hipStream_t s) override { if (failed) return; down(dev, n, s); chk(cb.allreduce_sum(cb.user, stage.p, n), "allreduce_sum"); up(dev, n, s); }
     const char *name() const override { return "host callbacks"; }
     ~HostTransport() override { stage.release(); }
 };
@@ -2168,9 +2172,11 @@ int shard_iterate(april_graph_t *g, april_graph_cholesky_param_t *param, int n) 
         hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
                            (double *)nullptr, (double *)nullptr, (const int *)nullptr, (int *)nullptr);
         HIPCHECK(hipGetLastError());
+        if (T && T->failed) break;
     }
     HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
+    if (T && T->failed) return -6;
     c.st.not_spd = c.h_bad.p[0] != 0;
     return c.h_bad.p[0] ? -2 : 0;
 }
@@ -2192,6 +2198,7 @@ int shard_gather_states(april_graph_t *g, april_graph_cholesky_param_t *param) {
         S.d_scratch.need((size_t)9 * N);
         hipLaunchKernelGGL(k_mask_owned, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, S.d_nown.p, S.rank, gp.d_state.p, gp.d_lp.p, gp.d_dx.p, S.d_scratch.p);
         S.tr->allreduce_sum(S.d_scratch.p, (long long)9 * N, s);
+        if (S.tr->failed) { HIPCHECK(hipStreamSynchronize(s)); return -6; }
         HIPCHECK(hipMemcpyAsync(gp.d_state.p, S.d_scratch.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
         HIPCHECK(hipMemcpyAsync(gp.d_lp.p, S.d_scratch.p + (size_t)3 * N, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
         HIPCHECK(hipMemcpyAsync(gp.d_dx.p, S.d_scratch.p + (size_t)6 * N, (size_t)24 * N, hipMemcpyDeviceToDevice, s));

@@ -301,7 +301,7 @@ int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, doubl
  *                    1 -> transfers {level, front, src, dst, (unused), packed count in doubles};
  *                    2 -> broadcasts {level, front, owner, first position, blocks}; 3 -> owner rank per front
  * Return codes: 0 ok; -1 bad arguments / no shard_begin; -2 non-positive pivot; -4 foreign factor types; -5 librccl.so not
- * loadable; -6 RCCL error; -7 no transport attached. */
+ * loadable; -6 communication error (RCCL or host callback; message on stderr); -7 no transport attached. */
 typedef struct aprilsam_amd_host_comm {
     void *user;                                                           /* passed back to every callback */
     int (*send)(void *user, const double *buf, long long count, int dst);           /* blocking; 0 = ok */

@@ -3,8 +3,9 @@
     max-over-ranks timing, aggregate throughput).  No data-path collective — M3500 does not shard.
 (2) the nested-dissection subtree sharding of large graphs: ownership map and exchange lists (host logic of
     aprilsam_amd_shard_begin, reachable without a GPU through aprilsam_amd_shard_plan), and the exchange SCHEDULE of
-    aprilsam_amd/shard.py driven by two gloo ranks with stand-in payloads: same order of sends / receives / broadcasts
-    as the GPU driver, every slab arrives where the parent lives, no deadlock."""
+    aprilsam_amd_shard_iterate (csrc/solver.hip.cpp; host-callback transport = blocking send / recv / broadcast in list
+    order) driven by two gloo ranks with stand-in payloads: same order of sends / receives / broadcasts as the library,
+    every slab arrives where the parent lives, no deadlock."""
 import os
 import sys
 
@@ -97,7 +98,7 @@ def _shard_worker(rank, world, port, out):
     xfer, bcast, owner = P.shard[world]
     nlev = int(P.front_level.max()) + 1
     got, sent = [], []
-    # the schedule of aprilsam_amd/shard.py::ShardedSolver.iterate with stand-in payloads (front id, packed count)
+    # the schedule of aprilsam_amd_shard_iterate (host-callback transport) with stand-in payloads (front id, packed count)
     for l in range(nlev):
         for lev, front, src, dst, off, cnt in xfer[xfer[:, 0] == l]:
             buf = torch.zeros(3, dtype=torch.float64)
