@@ -73,6 +73,8 @@ static void load_env_options() {
         v = g_opt.inc_fast; envd("APRILSAM_AMD_INC_FAST", &v); g_opt.inc_fast = (int)v;
         v = g_opt.block_factor; envd("APRILSAM_AMD_BLOCK_FACTOR", &v); g_opt.block_factor = (int)v;
         v = g_opt.fused_panel; envd("APRILSAM_AMD_FUSED_PANEL", &v); g_opt.fused_panel = (int)v;
+        v = g_opt.persist; envd("APRILSAM_AMD_PERSIST", &v); g_opt.persist = (int)v;
+        v = g_opt.persist_max_fronts; envd("APRILSAM_AMD_PERSIST_MAX_FRONTS", &v); g_opt.persist_max_fronts = (int)v;
         v = g_opt.batch_extend; envd("APRILSAM_AMD_BATCH_EXTEND", &v); g_opt.batch_extend = (int)v;
         v = g_opt.extend_tail_fronts; envd("APRILSAM_AMD_EXTEND_TAIL_FRONTS", &v); g_opt.extend_tail_fronts = (int)v;
     });
@@ -440,6 +442,7 @@ struct Context {
     // incremental bookkeeping (aprilsam.c:741-751, 566-575)
     bool have_fact = false;               // a batch factorisation exists (reference: param->chol != NULL)
     int plan_pin = 0;                     // pin_last the plan was built with
+    int plan_persist = 0;                 // persist options the launch tables were built with
     int same_topo_batches = 0;            // batch calls on an extended (base + tail fronts) plan whose topology did not change since the previous call
     bool want_inc = false;                // the param has been used incrementally: plan uploads reserve the append slack
     int batch_nodes = 0;                  // #nodes at the last batch step (those carry the Tikhonov term)
@@ -458,6 +461,12 @@ struct Context {
         return la_ev[la_next++];
     }
     // captured numeric phase
+    // multi-level ("persistent") launches of the batch path: the top levels of the tree, where a level holds only a handful
+    // of fronts, run as ONE launch for the factorisation and ONE for the back substitution, fronts waiting on per-front
+    // dependency flags instead of on kernel boundaries (kernels.hip.h: wait_flag / publish_flag)
+    int persist_l0 = -1;                  // first level of the multi-level launch, -1: none
+    int p_up_off = 0, p_up_n = 0, p_dn_off = 0, p_dn_n = 0, p_nt = 1024; size_t p_up_lds = 0, p_dn_lds = 0; long long p_up_full = 0;
+    DBuf<int> d_flags, d_flevel;
     hipGraphExec_t gexec = nullptr;
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
     // the same phase as the API call runs it: first kernel reads the caller's states from the pinned mirror, last kernel
@@ -467,7 +476,7 @@ struct Context {
     double lambda_val = -1; int lambda_N = -1;     // what d_lambda currently holds (uniform batch value), -1: unknown
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
-        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release();
+        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release(); d_flags.release(); d_flevel.release();
         if (gexec) (void)hipGraphExecDestroy(gexec);
         gexec = nullptr;
         if (gexec_api) (void)hipGraphExecDestroy(gexec_api);
@@ -680,6 +689,30 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
         if (c.levels[l].solve_lds > 160 * 1024)       // k_backsolve keeps x over a front's rows in LDS (~19 000 scalar rows)
             fatal("a frontal matrix has more rows than the back-substitution kernel can hold in LDS (an unsplittable dense region "
                   "of more than ~6000 poses); this build does not tile the solve of such a front");
+    // ---- multi-level launch over the top of the tree (small fronts only, few per level) ------------------------------
+    c.persist_l0 = -1;
+    if (g_opt.persist && !lay && P.nLevels >= 3) {
+        int l0 = P.nLevels, cnt = 0;
+        const int nt_top = c.levels[P.nLevels - 1].small_nt;
+        for (int l = P.nLevels - 1; l >= 1; l--) {
+            const LevelPlan &L = c.levels[l];
+            if (L.n_big > 0 || L.bs_gemv.grid > 0 || L.small_nt != nt_top || L.n_small != L.n_all || cnt + L.n_small > g_opt.persist_max_fronts) break;
+            cnt += L.n_small; l0 = l;
+        }
+        if (P.nLevels - l0 >= 2) {
+            c.persist_l0 = l0; c.p_nt = nt_top; c.p_up_lds = 0; c.p_dn_lds = 0; c.p_up_full = 0;
+            c.p_up_off = (int)tab.size(); c.p_up_n = cnt;
+            for (int l = l0; l < P.nLevels; l++) {                     // children before parents: dependencies have lower workgroup ids
+                const LevelPlan &L = c.levels[l];
+                for (int k = 0; k < L.n_small; k++) tab.push_back(tab[L.small_off + k]);
+                c.p_up_lds = std::max(c.p_up_lds, L.small_lds); c.p_up_full = std::max(c.p_up_full, L.full_limit); c.p_dn_lds = std::max(c.p_dn_lds, L.solve_lds);
+            }
+            c.p_dn_off = (int)tab.size(); c.p_dn_n = cnt;
+            for (int l = P.nLevels - 1; l >= l0; l--) { const LevelPlan &L = c.levels[l]; for (int k = 0; k < L.n_all; k++) tab.push_back(tab[L.all_off + k]); }
+            c.d_flags.need((size_t)2 * P.nF); c.d_flevel.need(P.nF);
+            HIPCHECK(hipMemcpyAsync(c.d_flevel.p, P.f_level.data(), (size_t)P.nF * 4, hipMemcpyHostToDevice, s));
+        }
+    }
     if (tab.empty()) tab.push_back(0);
     c.d_tab.need(tab.size() + INC_TAB_);
     c.inc.tab_used = (long long)tab.size();
@@ -724,12 +757,21 @@ static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic 
 }
 
 // k_front_small with the configured workgroup size (option small_threads: 256 / 512 / 1024)
+// the multi-level launch of the factorisation: every small front of levels >= persist_l0
+static void launch_front_persist(Context &c, hipStream_t s) {
+    const int *list = c.d_tab.p + c.p_up_off;
+    int *fl = c.d_flags.p;
+    if (c.p_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(c.p_up_n), dim3(1024), c.p_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, g_opt.block_factor, fl, 1);
+    else if (c.p_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(c.p_up_n), dim3(512), c.p_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, g_opt.block_factor, fl, 1);
+    else hipLaunchKernelGGL(k_front_small<256>, dim3(c.p_up_n), dim3(256), c.p_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, g_opt.block_factor, fl, 1);
+}
+
 static void launch_front_small(Context &c, const LevelPlan &L, hipStream_t s, const int *tab = nullptr) {
     if (!tab) tab = c.d_tab.p;
     const int nt = L.small_nt;
-    if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
-    else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
-    else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor);
+    if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor, (int *)nullptr, 0);
+    else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor, (int *)nullptr, 0);
+    else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor, (int *)nullptr, 0);
 }
 
 // panel steps of the big fronts of one level: per NB-column panel {diagonal block, row solves, narrow update};
@@ -850,9 +892,17 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     toc();
     if (ev) HIPCHECK(hipEventRecord(ev[1], s));
     c.la_next = 0;
-    for (int l = 0; l < P.nLevels; l++) enqueue_factor_level(c, c.levels[l], s, tic, toc, !ktime && g_opt.lookahead);
+    const int l0 = c.persist_l0 >= 0 ? c.persist_l0 : P.nLevels;        // levels >= l0: one multi-level launch each way
+    if (l0 < P.nLevels) hipLaunchKernelGGL(k_init_flags, dim3((P.nF + TPB - 1) / TPB), dim3(TPB), 0, s, P.nF, c.d_flevel.p, l0, c.d_flags.p, c.d_flags.p + P.nF);
+    for (int l = 0; l < l0; l++) enqueue_factor_level(c, c.levels[l], s, tic, toc, !ktime && g_opt.lookahead);
+    if (l0 < P.nLevels) { tic(K_FRONT_SMALL); launch_front_persist(c, s); toc(); }
     if (ev) HIPCHECK(hipEventRecord(ev[2], s));
-    for (int l = P.nLevels - 1; l >= 0; l--) {
+    if (l0 < P.nLevels) {
+        tic(K_BACKSOLVE);
+        hipLaunchKernelGGL(k_backsolve, dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, c.dp, c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + P.nF, 1, c.d_bad.p);
+        toc();
+    }
+    for (int l = l0 - 1; l >= 0; l--) {
         launch_backsolve(c, c.levels[l], s, tic, toc);
     }
     tic(K_UPDATE);
@@ -929,14 +979,14 @@ static double device_chi2(GraphPack &gp) {     // chi^2 at d_state; synchronises
 static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g, bool upload = true) {
     const int N = gp.N, F = gp.F;
     bool same = c.have_plan && c.patN == N && (int)c.pat.size() == 2 * F && c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last &&
-                c.inc.t_first.empty();        // (a plan extended by tail fronts is only driven by inc_fast_step)
+                c.plan_persist == g_opt.persist * 100000 + g_opt.persist_max_fronts && c.inc.t_first.empty();        // (a plan extended by tail fronts is only driven by inc_fast_step)
     if (same) {
         for (int i = 0; i < F && same; i++) same = c.pat[2 * i] == gp.h_fa.p[i] && c.pat[2 * i + 1] == gp.h_fb.p[i];
     }
     if (same) return true;
     c.pat.resize((size_t)2 * F);
     for (int i = 0; i < F; i++) { c.pat[2 * i] = gp.h_fa.p[i]; c.pat[2 * i + 1] = gp.h_fb.p[i]; }
-    c.patN = N; c.plan_pin = g_opt.pin_last;
+    c.patN = N; c.plan_pin = g_opt.pin_last; c.plan_persist = g_opt.persist * 100000 + g_opt.persist_max_fronts;
     std::vector<double> xy((size_t)2 * N);
     for (int i = 0; i < N; i++) { xy[2 * i] = gp.h_state.p[3 * i]; xy[2 * i + 1] = gp.h_state.p[3 * i + 1]; }
     const double tb0 = now_ms();
@@ -2352,6 +2402,8 @@ int api_set_option(const char *name, double v) {
     else if (k == "block_factor") g_opt.block_factor = (int)v;
     else if (k == "pin_last") g_opt.pin_last = (int)v;
     else if (k == "fused_panel") g_opt.fused_panel = (int)v;
+    else if (k == "persist") g_opt.persist = (int)v;
+    else if (k == "persist_max_fronts") g_opt.persist_max_fronts = (int)v;
     else if (k == "batch_extend") g_opt.batch_extend = (int)v;
     else if (k == "extend_tail_fronts") g_opt.extend_tail_fronts = (int)v;
     else return -1;
