@@ -705,7 +705,8 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
             for (int l = l0; l < P.nLevels; l++) {                     // children before parents: dependencies have lower workgroup ids
                 const LevelPlan &L = c.levels[l];
                 for (int k = 0; k < L.n_small; k++) tab.push_back(tab[L.small_off + k]);
-                c.p_up_lds = std::max(c.p_up_lds, L.small_lds); c.p_up_full = std::max(c.p_up_full, L.full_limit); c.p_dn_lds = std::max(c.p_dn_lds, L.solve_lds);
+                c.p_up_lds = std::max(c.p_up_lds, L.small_lds); c.p_up_full = std::max(c.p_up_full, L.full_limit);
+                for (int k = 0; k < L.n_all; k++) { const int t = tab[L.all_off + k]; c.p_dn_lds = std::max(c.p_dn_lds, backsolve_lds(P.cols(t), 3 * P.f_nsb[t], true)); }
             }
             c.p_dn_off = (int)tab.size(); c.p_dn_n = cnt;
             for (int l = P.nLevels - 1; l >= l0; l--) { const LevelPlan &L = c.levels[l]; for (int k = 0; k < L.n_all; k++) tab.push_back(tab[L.all_off + k]); }
@@ -739,7 +740,8 @@ static void set_small_attr() {
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
 }
 
@@ -752,7 +754,7 @@ static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic 
     if (L.bs_gemv.grid > 0)
         hipLaunchKernelGGL(k_backsolve_gemv, dim3(L.bs_gemv.grid), dim3(TPB), 0, s, c.dp, tab + L.bs_gemv.list_off, tab + L.bs_gemv.pre_off,
                            L.bs_gemv.n, c.d_pool.p, c.d_x.p);
-    hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0);
+    hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, (int *)nullptr);
     toc();
 }
 
@@ -899,7 +901,7 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     if (ev) HIPCHECK(hipEventRecord(ev[2], s));
     if (l0 < P.nLevels) {
         tic(K_BACKSOLVE);
-        hipLaunchKernelGGL(k_backsolve, dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, c.dp, c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + P.nF, 1, c.d_bad.p);
+        hipLaunchKernelGGL((k_backsolve_t<true>), dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, c.dp, c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + P.nF, 1, c.d_bad.p);
         toc();
     }
     for (int l = l0 - 1; l >= 0; l--) {
@@ -1339,11 +1341,11 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         if (l >= I.nLev0 || needed) {
             if (bs_n[l] > 0) {
                 const size_t lds = l >= I.nLev0 ? solve_lds_of(nF0 + l - I.nLev0) : I.base_levels[l].solve_lds;
-                hipLaunchKernelGGL(k_backsolve, dim3((unsigned)bs_n[l]), dim3(TPB), lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0);
+                hipLaunchKernelGGL((k_backsolve_t<false>), dim3((unsigned)bs_n[l]), dim3(TPB), lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr);
             }
         } else {                                     // every pose is visited: all base fronts, level by level
             const LevelPlan &L = I.base_levels[l];
-            hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0);
+            hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr);
         }
     }
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
@@ -1615,7 +1617,7 @@ void inc_solve_only(april_graph_t *g, april_graph_cholesky_param_t *param) {
     set_small_attr();
     for (int l = P.nLevels - 1; l >= 0; l--) {
         const LevelPlan &L = c.levels[l];
-        hipLaunchKernelGGL(k_backsolve, dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0);
+        hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr);
     }
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
     HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
