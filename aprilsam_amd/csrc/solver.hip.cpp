@@ -466,7 +466,7 @@ struct Context {
     // dependency flags instead of on kernel boundaries (kernels.hip.h: wait_flag / publish_flag)
     int persist_l0 = -1;                  // first level of the multi-level launch, -1: none
     int p_up_off = 0, p_up_n = 0, p_dn_off = 0, p_dn_n = 0, p_nt = 1024; size_t p_up_lds = 0, p_dn_lds = 0; long long p_up_full = 0;
-    DBuf<int> d_flags, d_flevel;
+    DBuf<int> d_flags, d_flevel, d_perm;
     hipGraphExec_t gexec = nullptr;
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
     // the same phase as the API call runs it: first kernel reads the caller's states from the pinned mirror, last kernel
@@ -476,7 +476,7 @@ struct Context {
     double lambda_val = -1; int lambda_N = -1;     // what d_lambda currently holds (uniform batch value), -1: unknown
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
-        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release(); d_flags.release(); d_flevel.release();
+        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release(); d_flags.release(); d_flevel.release(); d_perm.release();
         if (gexec) (void)hipGraphExecDestroy(gexec);
         gexec = nullptr;
         if (gexec_api) (void)hipGraphExecDestroy(gexec_api);
@@ -677,6 +677,8 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.d_swap.need((size_t)P.F + INC_FACT_); c.d_pos.need((size_t)P.N + INC_NODES_);
     HIPCHECK(hipMemcpyAsync(c.d_swap.p, P.fac_swap.data(), P.F, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_pos.p, P.pos.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
+    c.d_perm.need((size_t)P.N);
+    HIPCHECK(hipMemcpyAsync(c.d_perm.p, P.perm.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
 
     // ---- launch tables -------------------------------------------------------------------------------------
     std::vector<int> tab;
@@ -747,14 +749,14 @@ static void set_small_attr() {
 
 // back substitution of one level: update-row products of the large fronts on many workgroups, then one workgroup per front
 template <class Tic, class Toc>
-static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, const int *tab = nullptr) {
+static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, const int *tab = nullptr, UpdArgs upd = UpdArgs{}) {
     if (!tab) tab = c.d_tab.p;
     if (!L.n_all) return;
     tic(K_BACKSOLVE);
     if (L.bs_gemv.grid > 0)
         hipLaunchKernelGGL(k_backsolve_gemv, dim3(L.bs_gemv.grid), dim3(TPB), 0, s, c.dp, tab + L.bs_gemv.list_off, tab + L.bs_gemv.pre_off,
                            L.bs_gemv.n, c.d_pool.p, c.d_x.p);
-    hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, (int *)nullptr);
+    hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, c.d_bad.p, upd);
     toc();
 }
 
@@ -884,7 +886,8 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     if (io_host) hipLaunchKernelGGL(k_load_states, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.d_state.p, gp.d_lp.p);
     tic(K_LINEARIZE);
     hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                       gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, unary_at_lp ? gp.d_upt.p : (const double *)nullptr);
+                       gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, unary_at_lp ? gp.d_upt.p : (const double *)nullptr,
+                       P.nF, c.d_flevel.p, c.persist_l0 >= 0 ? c.persist_l0 : 0, c.persist_l0 >= 0 ? c.d_flags.p : (int *)nullptr);
     if (!gp.host_idx.empty()) {         // host-evaluated factors: their blocks replace the null contributions written above
         const int nh = (int)gp.host_idx.size();
         HIPCHECK(hipMemcpyAsync(gp.d_hostH.p, gp.h_hostH.p, (size_t)33 * 8 * nh, hipMemcpyHostToDevice, s));
@@ -895,24 +898,22 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     if (ev) HIPCHECK(hipEventRecord(ev[1], s));
     c.la_next = 0;
     const int l0 = c.persist_l0 >= 0 ? c.persist_l0 : P.nLevels;        // levels >= l0: one multi-level launch each way
-    if (l0 < P.nLevels) hipLaunchKernelGGL(k_init_flags, dim3((P.nF + TPB - 1) / TPB), dim3(TPB), 0, s, P.nF, c.d_flevel.p, l0, c.d_flags.p, c.d_flags.p + P.nF);
     for (int l = 0; l < l0; l++) enqueue_factor_level(c, c.levels[l], s, tic, toc, !ktime && g_opt.lookahead);
     if (l0 < P.nLevels) { tic(K_FRONT_SMALL); launch_front_persist(c, s); toc(); }
     if (ev) HIPCHECK(hipEventRecord(ev[2], s));
+    // the state update of a front's own poses rides on its back substitution (no kernel of its own); the last launch also
+    // mirrors the pivot flag for the API call
+    UpdArgs upd{ c.d_perm.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p, io_host ? gp.h_lp.p : nullptr, io_host ? gp.h_dx.p : nullptr, nullptr };
     if (l0 < P.nLevels) {
+        UpdArgs u = upd; if (l0 == 0) u.bad_out = io_host ? c.h_bad.p : nullptr;
         tic(K_BACKSOLVE);
-        hipLaunchKernelGGL((k_backsolve_t<true>), dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, c.dp, c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + P.nF, 1, c.d_bad.p);
+        hipLaunchKernelGGL((k_backsolve_t<true>), dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, c.dp, c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + P.nF, 1, c.d_bad.p, u);
         toc();
     }
     for (int l = l0 - 1; l >= 0; l--) {
-        launch_backsolve(c, c.levels[l], s, tic, toc);
+        UpdArgs u = upd; if (l == 0) u.bad_out = io_host ? c.h_bad.p : nullptr;
+        launch_backsolve(c, c.levels[l], s, tic, toc, nullptr, u);
     }
-    tic(K_UPDATE);
-    if (io_host) hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
-                                    gp.h_lp.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);
-    else hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
-                            (double *)nullptr, (double *)nullptr, (const int *)nullptr, (int *)nullptr);
-    toc();
     if (ev) HIPCHECK(hipEventRecord(ev[3], s));
     HIPCHECK(hipGetLastError());
 }
@@ -1341,11 +1342,11 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         if (l >= I.nLev0 || needed) {
             if (bs_n[l] > 0) {
                 const size_t lds = l >= I.nLev0 ? solve_lds_of(nF0 + l - I.nLev0) : I.base_levels[l].solve_lds;
-                hipLaunchKernelGGL((k_backsolve_t<false>), dim3((unsigned)bs_n[l]), dim3(TPB), lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr);
+                hipLaunchKernelGGL((k_backsolve_t<false>), dim3((unsigned)bs_n[l]), dim3(TPB), lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr, UpdArgs{});
             }
         } else {                                     // every pose is visited: all base fronts, level by level
             const LevelPlan &L = I.base_levels[l];
-            hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr);
+            hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr, UpdArgs{});
         }
     }
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
@@ -1617,7 +1618,7 @@ void inc_solve_only(april_graph_t *g, april_graph_cholesky_param_t *param) {
     set_small_attr();
     for (int l = P.nLevels - 1; l >= 0; l--) {
         const LevelPlan &L = c.levels[l];
-        hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr);
+        hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr, UpdArgs{});
     }
     hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
     HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
