@@ -444,6 +444,7 @@ struct Context {
     int plan_pin = 0;                     // pin_last the plan was built with
     int plan_persist = 0;                 // persist options the launch tables were built with
     int same_topo_batches = 0;            // batch calls on an extended (base + tail fronts) plan whose topology did not change since the previous call
+    bool used_inc = false;                // april_graph_cholesky_inc has been called on this param
     bool want_inc = false;                // the param has been used incrementally: plan uploads reserve the append slack
     int batch_nodes = 0;                  // #nodes at the last batch step (those carry the Tikhonov term)
     IncState inc;
@@ -712,10 +713,11 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
             }
             c.p_dn_off = (int)tab.size(); c.p_dn_n = cnt;
             for (int l = P.nLevels - 1; l >= l0; l--) { const LevelPlan &L = c.levels[l]; for (int k = 0; k < L.n_all; k++) tab.push_back(tab[L.all_off + k]); }
-            c.d_flags.need((size_t)2 * P.nF); c.d_flevel.need(P.nF);
-            HIPCHECK(hipMemcpyAsync(c.d_flevel.p, P.f_level.data(), (size_t)P.nF * 4, hipMemcpyHostToDevice, s));
         }
     }
+    // (dependency flags / front levels: also used by the extended-plan batch step, whose tail fronts get levels of their own)
+    c.d_flags.need((size_t)2 * (P.nF + MAX_TAIL_FRONTS)); c.d_flevel.need((size_t)P.nF + MAX_TAIL_FRONTS);
+    HIPCHECK(hipMemcpyAsync(c.d_flevel.p, P.f_level.data(), (size_t)P.nF * 4, hipMemcpyHostToDevice, s));
     if (tab.empty()) tab.push_back(0);
     c.d_tab.need(tab.size() + INC_TAB_);
     c.inc.tab_used = (long long)tab.size();
@@ -1273,6 +1275,33 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
     }
     for (int l = 0; l < nLev; l++) if ((size_t)(std::max(dl[l].n_big, dl[l].n_diag_slots) + 64) * NB * (NB + 1) > c.d_diag.cap) return false;
+    // batch on the extended plan: levels >= 1 as ONE multi-level launch per sweep (see enqueue_numeric), when they hold small
+    // fronts only
+    int mp_up_off = 0, mp_dn_off = 0, mp_n = 0, mp_nt = 0; size_t mp_up_lds = 0, mp_dn_lds = 0; long long mp_full = 0;
+    bool mp = batch && g_opt.persist && nLev >= 3;
+    if (mp) {
+        mp_nt = dl[nLev - 1].small_nt;
+        for (int l = 1; l < nLev && mp; l++) {
+            const LevelPlan &L = dl[l];
+            mp = L.n_big == 0 && L.bs_gemv.grid == 0 && L.small_nt == mp_nt && L.n_small == L.n_all;
+            mp_n += L.n_all;
+        }
+        mp = mp && mp_n <= g_opt.persist_max_fronts && (size_t)2 * nFr <= c.d_flags.cap;
+    }
+    if (mp) {
+        const int sh = (int)I.tab_used;
+        const size_t tab_size0 = tab.size();
+        mp_up_off = sh + (int)tab.size();
+        for (int l = 1; l < nLev; l++) {
+            const LevelPlan &L = dl[l];
+            for (int k = 0; k < L.n_small; k++) tab.push_back(tab[L.small_off - sh + k]);
+            mp_up_lds = std::max(mp_up_lds, L.small_lds); mp_full = std::max(mp_full, L.full_limit);
+            for (int k = 0; k < L.n_all; k++) { const int t = tab[L.all_off - sh + k]; mp_dn_lds = std::max(mp_dn_lds, backsolve_lds(3 * (nsb_of(t) + I.cur_nub[t]), 3 * nsb_of(t), true)); }
+        }
+        mp_dn_off = sh + (int)tab.size();
+        for (int l = nLev - 1; l >= 1; l--) { const LevelPlan &L = dl[l]; for (int k = 0; k < L.n_all; k++) tab.push_back(tab[L.all_off - sh + k]); }
+        if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap || mp_dn_lds > 160 * 1024) { mp = false; tab.resize(tab_size0); }
+    }
     auto solve_lds_of = [&](int t) { return (size_t)(3 * (nsb_of(t) + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8; };
     for (int t = 0; t < nFr; t++) if (I.need[t] && solve_lds_of(t) > 160 * 1024) return false;
     c.st.reserved0 = (int)fd_dirty.size();              // fronts regenerated by this step (tools/inc_hist.py)
@@ -1316,6 +1345,11 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         PL.add(c.d_lambda.p, c.h_lambda.data(), (size_t)N * 8);
         c.lambda_N = -1;
     }
+    if (mp) {            // levels of the tail fronts for the dependency flags (base fronts: uploaded with the plan)
+        I.st_ids.resize(nT);
+        for (int i = 0; i < nT; i++) I.st_ids[i] = I.nLev0 + i;
+        PL.add(c.d_flevel.p + nF0, I.st_ids.data(), (size_t)nT * 4);
+    }
     PL.launch(s);
     if (batch) hipLaunchKernelGGL(k_load_states, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.d_state.p, gp.d_lp.p);      // l_point <- state
     else hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
@@ -1323,12 +1357,21 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     set_small_attr();
     if (batch)
         hipLaunchKernelGGL(k_linearize, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p);
+                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, (const double *)nullptr,
+                           nFr, c.d_flevel.p, 1, mp ? c.d_flags.p : (int *)nullptr);
     else if (F > Fold)
         hipLaunchKernelGGL(k_linearize, dim3((F - Fold + TPB - 1) / TPB), dim3(TPB), 0, s, Fold, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                            gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);      // new priors: at the node's current state
     for (int l = 0; l < nLev; l++) {
         if (lev_dirty[l].empty()) continue;
+        if (mp && l >= 1) {
+            if (l > 1) continue;
+            const int *list = c.d_tab.p + mp_up_off;
+            if (mp_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(mp_n), dim3(1024), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, g_opt.block_factor, c.d_flags.p, 1);
+            else if (mp_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(mp_n), dim3(512), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, g_opt.block_factor, c.d_flags.p, 1);
+            else hipLaunchKernelGGL(k_front_small<256>, dim3(mp_n), dim3(256), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, g_opt.block_factor, c.d_flags.p, 1);
+            continue;
+        }
         const LevelPlan &L = dl[l];
         if (L.n_small) launch_front_small(c, L, s);
         if (L.n_big) {
@@ -1337,7 +1380,9 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             enqueue_big_steps(c, L, s, [](int) {}, []() {});
         }
     }
+    if (mp) hipLaunchKernelGGL((k_backsolve_t<true>), dim3(mp_n), dim3(TPB), mp_dn_lds, s, c.dp, c.d_tab.p + mp_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + nFr, 1, c.d_bad.p, UpdArgs{});
     for (int l = nLev - 1; l >= 0; l--) {
+        if (mp && l >= 1) continue;
         if (batch) { launch_backsolve(c, dl[l], s, [](int) {}, []() {}); continue; }
         if (l >= I.nLev0 || needed) {
             if (bs_n[l] > 0) {
@@ -1425,7 +1470,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     // while the GPU works: a param that is used incrementally needs the reference's elimination tree of THIS batch step for
     // its next april_graph_cholesky_inc (refmodel.cpp: the reference's own min-degree order, ~1 ms of integer work on M3500)
     bool model_ready = false;
-    if (c.want_inc && gp.host_idx.empty()) { c.model.batch(N, F, gp.h_fa.p, gp.h_fb.p); model_ready = true; }
+    if (c.used_inc && gp.host_idx.empty()) { c.model.batch(N, F, gp.h_fa.p, gp.h_fb.p); model_ready = true; }      // (not for params that only ever see batch calls)
     HIPCHECK(hipStreamSynchronize(gp.stream));
     const double t4 = now_ms();
     c.st.not_spd = c.h_bad.p[0] != 0;
@@ -1518,7 +1563,7 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     ensure_device();
     Context &c = ctx_for(param);
     GraphPack &gp = pack_for(g);
-    c.want_inc = true;
+    c.want_inc = true; c.used_inc = true;
     const double t0 = now_ms();
     pack_factors(gp, g, false);
     pack_states(gp, g, true, false);                 // pinned mirrors only: the fast path reads them from its first kernel
