@@ -746,6 +746,7 @@ static void set_small_attr() {
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
 }
 
@@ -758,7 +759,10 @@ static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic 
     if (L.bs_gemv.grid > 0)
         hipLaunchKernelGGL(k_backsolve_gemv, dim3(L.bs_gemv.grid), dim3(TPB), 0, s, c.dp, tab + L.bs_gemv.list_off, tab + L.bs_gemv.pre_off,
                            L.bs_gemv.n, c.d_pool.p, c.d_x.p);
-    hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, c.d_bad.p, upd);
+    if (L.solve_lds >= (size_t)(BS_TALL_ROWS + NB + 8 + NB * (NB + 1)) * 8)
+        hipLaunchKernelGGL((k_backsolve_t<false, true>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, c.d_bad.p, upd);
+    else
+        hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, c.d_bad.p, upd);
     toc();
 }
 

@@ -1,4 +1,4 @@
-"""debug: per-level phase breakdown of k_backsolve on M3500 (sets APRILSAM_AMD_KPROF=1): python tools/backsolve_times.py"""
+"""debug: per-level phase breakdown of k_backsolve (sets APRILSAM_AMD_KPROF=2): python tools/backsolve_times.py [--lattice K]"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, "/root/repo")
@@ -6,7 +6,7 @@ os.environ["APRILSAM_AMD_KPROF"] = "2"
 from aprilsam_amd import datasets, host
 from tests.support.mf_emulator import PlanView
 lib = host.SolverLib()
-arr = datasets.m3500_batch()
+arr = lib.lattice_arrays(int(sys.argv[sys.argv.index("--lattice") + 1])) if "--lattice" in sys.argv else datasets.m3500_batch()
 g = lib.new_graph(); g.build_from_arrays(*arr); p = lib.new_param()
 lib.set_option("use_graph", 0)
 for _ in range(3): g.cholesky(p)
@@ -19,4 +19,4 @@ for l in range(P.nLevels - 1, -1, -1):
     big = max(fr, key=lambda t: buf[t, 7] - buf[t, 4])
     b = buf[big] * 0.01
     span = (max(buf[t, 7] for t in fr) - min(buf[t, 4] for t in fr)) * 0.01
-    print(f"level {l}: span {span:.1f} | slowest nsb={P.front_nsb[big]} nub={P.front_nub[big]}: gather {b[5]-b[4]:.2f} first products {b[6]-b[5]:.2f} rest {b[7]-b[6]:.2f} total {b[7]-b[4]:.2f}")
+    print(f"level {l}: span {span:.1f} | slowest nsb={P.front_nsb[big]} nub={P.front_nub[big]}: gather {b[5]-b[4]:.2f} first products {b[6]-b[5]:.2f} rest {b[7]-b[6]:.2f} total {b[7]-b[4]:.2f} | loop: products {b[8]:.2f} sums+barrier {b[9]:.2f} in-wave solve+barrier {b[10]:.2f}")
