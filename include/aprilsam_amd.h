@@ -245,7 +245,14 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *                       or when the topology stops changing, a full re-plan follows.  0 = re-plan on every topology change
  *   "pin_last"          k > 0: the k newest poses are kept out of the nested dissection and form the root front ("recent
  *                       poses last", cf. aprilsam.c:1021-1098); default 0, measured effect in profiles/r02_inc_hist.json
- *   "inc_fast"          0 = every incremental step re-plans (default 1: frozen base plan + dirty root paths) */
+ *   "inc_fast"          0 = every incremental step re-plans (default 1: frozen base plan + dirty root paths)
+ *   "persist"           1 (default): the top levels of the elimination tree -- as many as hold at most "persist_max_fronts"
+ *                       (default 240) single-workgroup fronts -- run as ONE launch per sweep, fronts synchronised by
+ *                       per-front dependency flags; 0 = one launch per level
+ *   "fused_panel"       0 = diagonal block and row solves of a multi-tile panel step as two kernels (default 1: one)
+ *   "lookahead"         1 = wide trailing updates split, the far part on a side stream (default 0: measured no gain)
+ *   "linearize_staged_min"  graphs with at least this many factors (default 32768) write the J^T W J blocks out through
+ *                       LDS with coalesced stores; smaller ones store directly (one latency chain less) */
 int aprilsam_amd_set_option(const char *name, double value);
 
 /* ---- device-resident benchmark/driver API: states stay in HBM between iterations -------------

@@ -8,7 +8,7 @@ os.environ["APRILSAM_AMD_KPROF"] = "1"
 from aprilsam_amd import datasets, host
 from tests.support.mf_emulator import PlanView
 lib = host.SolverLib()
-arr = datasets.m3500_batch() if "--lattice" not in sys.argv else lib.lattice_arrays(120)
+arr = datasets.m3500_batch() if "--lattice" not in sys.argv else lib.lattice_arrays(316)
 g = lib.new_graph(); g.build_from_arrays(*arr); p = lib.new_param()
 lib.set_option("use_graph", 0)
 for _ in range(3):
