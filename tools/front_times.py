@@ -29,4 +29,4 @@ for l in range(P.nLevels):
     span = max(T[t, 3] for t in fr) - min(T[t, 0] for t in fr)
     big = max(fr, key=lambda t: T[t, 3] - T[t, 0])
     print(f"level {l}: {len(fr):4d} fronts  span {span:7.1f} us | mean asm {a[:,0].mean():6.1f} fac {a[:,1].mean():6.1f} store {a[:,2].mean():6.1f} | "
-          f"slowest nsb={P.front_nsb[big]} nub={P.front_nub[big]} nch={P.ch_ptr[big+1]-P.ch_ptr[big]}: asm {T[big,1]-T[big,0]:.1f} fac {T[big,2]-T[big,1]:.1f} store {T[big,3]-T[big,2]:.1f} | chain {buf[big,8]*0.01:.1f} syrk {buf[big,9]*0.01:.1f} | asm: zero {(buf[big,4]-buf[big,0])*0.01:.1f} dest {(buf[big,5]-buf[big,4])*0.01:.1f} fill {(buf[big,6]-buf[big,5])*0.01:.1f} (n={buf[big,7]}) rest {(buf[big,1]-buf[big,6])*0.01:.1f} (after wait {(buf[big,1]-buf[big,11])*0.01 if buf[big,11] else 0:.1f})")
+          f"slowest nsb={P.front_nsb[big]} nub={P.front_nub[big]} nch={P.ch_ptr[big+1]-P.ch_ptr[big]}: asm {T[big,1]-T[big,0]:.1f} fac {T[big,2]-T[big,1]:.1f} store {T[big,3]-T[big,2]:.1f} | chain+far {buf[big,8]*0.01:.1f} next-block syrk {buf[big,9]*0.01:.1f} (pure look-ahead chains {buf[big,15]*0.01:.2f} us = {buf[big,10]} cycles) | asm: zero {(buf[big,4]-buf[big,0])*0.01:.1f} dest {(buf[big,5]-buf[big,4])*0.01:.1f} fill {(buf[big,6]-buf[big,5])*0.01:.1f} (n={buf[big,7]}) rest {(buf[big,1]-buf[big,6])*0.01:.1f} (after wait {(buf[big,1]-buf[big,11])*0.01 if buf[big,11] else 0:.1f})")
