@@ -76,6 +76,7 @@ static void load_env_options() {
         v = g_opt.persist; envd("APRILSAM_AMD_PERSIST", &v); g_opt.persist = (int)v;
         v = g_opt.persist_max_fronts; envd("APRILSAM_AMD_PERSIST_MAX_FRONTS", &v); g_opt.persist_max_fronts = (int)v;
         v = g_opt.linearize_staged_min; envd("APRILSAM_AMD_LINEARIZE_STAGED_MIN", &v); g_opt.linearize_staged_min = (int)v;
+        v = g_opt.wave_backsolve; envd("APRILSAM_AMD_WAVE_BACKSOLVE", &v); g_opt.wave_backsolve = (int)v;
         v = g_opt.batch_extend; envd("APRILSAM_AMD_BATCH_EXTEND", &v); g_opt.batch_extend = (int)v;
         v = g_opt.extend_tail_fronts; envd("APRILSAM_AMD_EXTEND_TAIL_FRONTS", &v); g_opt.extend_tail_fronts = (int)v;
     });
@@ -385,6 +386,7 @@ struct LevelPlan {
     std::vector<int> diag_slot0;                               // per panel step: first slot of its factored diagonal blocks in d_diag (multi-tile steps)
     int wb_off = 0, n_wb = 0, n_diag_slots = 0;                // k_diag_writeback entries (3 ints each) of the level, slots used
     int all_off = 0, n_all = 0; size_t solve_lds = 0;          // every front (k_backsolve)
+    size_t solve_w_lds = 0; int maxns = 0;                     // ... in the column-per-lane form (k_backsolve_w: L panel in LDS), widest own part
     Launch bs_gemv{};                                          // fronts whose update-row product is spread over workgroups first (k_backsolve_gemv)
 };
 
@@ -467,7 +469,7 @@ struct Context {
     // of fronts, run as ONE launch for the factorisation and ONE for the back substitution, fronts waiting on per-front
     // dependency flags instead of on kernel boundaries (kernels.hip.h: wait_flag / publish_flag)
     int persist_l0 = -1;                  // first level of the multi-level launch, -1: none
-    int p_up_off = 0, p_up_n = 0, p_dn_off = 0, p_dn_n = 0, p_nt = 1024; size_t p_up_lds = 0, p_dn_lds = 0; long long p_up_full = 0;
+    int p_up_off = 0, p_up_n = 0, p_dn_off = 0, p_dn_n = 0, p_nt = 1024; size_t p_up_lds = 0, p_dn_lds = 0; long long p_up_full = 0; int p_dn_maxns = 0;
     DBuf<int> d_flags, d_flevel, d_perm;
     hipGraphExec_t gexec = nullptr;
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
@@ -545,6 +547,7 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     for (int t : fronts) {
         const int R = rows(t), C = cols(t);
         maxm = std::max<size_t>(maxm, C);
+        L.solve_w_lds = std::max(L.solve_w_lds, backsolve_lds(C, 3 * nsb_of(t), true)); L.maxns = std::max(L.maxns, 3 * nsb_of(t));
         const size_t lds_s = small_front_lds(R, C, nw), lds_p = panel_front_lds(R, 3 * nsb_of(t), nw);
         if (lds_s <= full_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_s); }
         else if (g_opt.panel_mode && lds_p <= small_max) { small.push_back(t); L.small_lds = std::max(L.small_lds, lds_p); }   // k_front_small, panel mode
@@ -704,13 +707,13 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
             cnt += L.n_small; l0 = l;
         }
         if (P.nLevels - l0 >= 2) {
-            c.persist_l0 = l0; c.p_nt = nt_top; c.p_up_lds = 0; c.p_dn_lds = 0; c.p_up_full = 0;
+            c.persist_l0 = l0; c.p_nt = nt_top; c.p_up_lds = 0; c.p_dn_lds = 0; c.p_up_full = 0; c.p_dn_maxns = 0;
             c.p_up_off = (int)tab.size(); c.p_up_n = cnt;
             for (int l = l0; l < P.nLevels; l++) {                     // children before parents: dependencies have lower workgroup ids
                 const LevelPlan &L = c.levels[l];
                 for (int k = 0; k < L.n_small; k++) tab.push_back(tab[L.small_off + k]);
                 c.p_up_lds = std::max(c.p_up_lds, L.small_lds); c.p_up_full = std::max(c.p_up_full, L.full_limit);
-                for (int k = 0; k < L.n_all; k++) { const int t = tab[L.all_off + k]; c.p_dn_lds = std::max(c.p_dn_lds, backsolve_lds(P.cols(t), 3 * P.f_nsb[t], true)); }
+                for (int k = 0; k < L.n_all; k++) { const int t = tab[L.all_off + k]; c.p_dn_lds = std::max(c.p_dn_lds, backsolve_lds(P.cols(t), 3 * P.f_nsb[t], true)); c.p_dn_maxns = std::max(c.p_dn_maxns, 3 * P.f_nsb[t]); }
             }
             c.p_dn_off = (int)tab.size(); c.p_dn_n = cnt;
             for (int l = P.nLevels - 1; l >= l0; l--) { const LevelPlan &L = c.levels[l]; for (int k = 0; k < L.n_all; k++) tab.push_back(tab[L.all_off + k]); }
@@ -747,6 +750,7 @@ static void set_small_attr() {
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_w, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
 }
@@ -760,7 +764,10 @@ static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic 
     if (L.bs_gemv.grid > 0)
         hipLaunchKernelGGL(k_backsolve_gemv, dim3(L.bs_gemv.grid), dim3(TPB), 0, s, c.dp, tab + L.bs_gemv.list_off, tab + L.bs_gemv.pre_off,
                            L.bs_gemv.n, c.d_pool.p, c.d_x.p);
-    if (L.solve_lds >= (size_t)(BS_TALL_ROWS + NB + 8 + NB * (NB + 1)) * 8)
+    // latency-bound levels of small fronts: column-per-lane form with the L panel in LDS (at least two workgroups per CU)
+    if (g_opt.wave_backsolve && L.bs_gemv.grid == 0 && L.n_all < g_opt.tp_fronts && L.maxns <= BSW_MAX_NS && L.solve_w_lds <= 80 * 1024)
+        hipLaunchKernelGGL(k_backsolve_w, dim3(L.n_all), dim3(TPB), L.solve_w_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, (int *)nullptr, c.d_bad.p, upd);
+    else if (L.solve_lds >= (size_t)(BS_TALL_ROWS + NB + 8 + NB * (NB + 1)) * 8)
         hipLaunchKernelGGL((k_backsolve_t<false, true>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, c.d_bad.p, upd);
     else
         hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, c.d_bad.p, upd);
@@ -919,7 +926,10 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     if (l0 < P.nLevels) {
         UpdArgs u = upd; if (l0 == 0) u.bad_out = io_host ? c.h_bad.p : nullptr;
         tic(K_BACKSOLVE);
-        hipLaunchKernelGGL((k_backsolve_t<true>), dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, c.dp, c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + P.nF, 1, c.d_bad.p, u);
+        if (g_opt.wave_backsolve && c.p_dn_maxns <= BSW_MAX_NS)
+            hipLaunchKernelGGL(k_backsolve_w, dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, c.dp, c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, c.d_flags.p + P.nF, c.d_bad.p, u);
+        else
+            hipLaunchKernelGGL((k_backsolve_t<true>), dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, c.dp, c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + P.nF, 1, c.d_bad.p, u);
         toc();
     }
     for (int l = l0 - 1; l >= 0; l--) {
@@ -1258,15 +1268,17 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             while (t >= 0 && !I.need[t]) { I.need[t] = 1; t = I.parent[t]; }
         }
     }
-    std::vector<int> bs_off(nLev, -1), bs_n(nLev, 0);
+    std::vector<int> bs_off(nLev, -1), bs_n(nLev, 0), bs_maxns(nLev, 0);
+    std::vector<size_t> bs_wlds(nLev, 0);
+    auto bs_note = [&](int l, int t) { bs_wlds[l] = std::max(bs_wlds[l], backsolve_lds(3 * (nsb_of(t) + I.cur_nub[t]), 3 * nsb_of(t), true)); bs_maxns[l] = std::max(bs_maxns[l], 3 * nsb_of(t)); };
     for (int l = nLev - 1; l >= 0; l--) {
         bs_off[l] = (int)(I.tab_used + (long long)tab.size());
         if (batch) continue;                       // (the full tables built above serve the back substitution too)
-        if (l >= I.nLev0) { const int t = nF0 + (l - I.nLev0); if (I.need[t]) { tab.push_back(t); bs_n[l] = 1; } }
+        if (l >= I.nLev0) { const int t = nF0 + (l - I.nLev0); if (I.need[t]) { tab.push_back(t); bs_n[l] = 1; bs_note(l, t); } }
         else if (needed) {
             for (int k = I.base_levels[l].all_off; k < I.base_levels[l].all_off + I.base_levels[l].n_all; k++) {
                 const int t = c.base_tab[k];
-                if (I.need[t]) { tab.push_back(t); bs_n[l]++; }
+                if (I.need[t]) { tab.push_back(t); bs_n[l]++; bs_note(l, t); }
             }
         }
     }
@@ -1287,7 +1299,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     for (int l = 0; l < nLev; l++) if ((size_t)(std::max(dl[l].n_big, dl[l].n_diag_slots) + 64) * NB * (NB + 1) > c.d_diag.cap) return false;
     // batch on the extended plan: levels >= 1 as ONE multi-level launch per sweep (see enqueue_numeric), when they hold small
     // fronts only
-    int mp_up_off = 0, mp_dn_off = 0, mp_n = 0, mp_nt = 0; size_t mp_up_lds = 0, mp_dn_lds = 0; long long mp_full = 0;
+    int mp_up_off = 0, mp_dn_off = 0, mp_n = 0, mp_nt = 0; size_t mp_up_lds = 0, mp_dn_lds = 0; long long mp_full = 0; int mp_dn_maxns = 0;
     bool mp = batch && g_opt.persist && nLev >= 3;
     if (mp) {
         mp_nt = dl[nLev - 1].small_nt;
@@ -1306,7 +1318,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             const LevelPlan &L = dl[l];
             for (int k = 0; k < L.n_small; k++) tab.push_back(tab[L.small_off - sh + k]);
             mp_up_lds = std::max(mp_up_lds, L.small_lds); mp_full = std::max(mp_full, L.full_limit);
-            for (int k = 0; k < L.n_all; k++) { const int t = tab[L.all_off - sh + k]; mp_dn_lds = std::max(mp_dn_lds, backsolve_lds(3 * (nsb_of(t) + I.cur_nub[t]), 3 * nsb_of(t), true)); }
+            for (int k = 0; k < L.n_all; k++) { const int t = tab[L.all_off - sh + k]; mp_dn_lds = std::max(mp_dn_lds, backsolve_lds(3 * (nsb_of(t) + I.cur_nub[t]), 3 * nsb_of(t), true)); mp_dn_maxns = std::max(mp_dn_maxns, 3 * nsb_of(t)); }
         }
         mp_dn_off = sh + (int)tab.size();
         for (int l = nLev - 1; l >= 1; l--) { const LevelPlan &L = dl[l]; for (int k = 0; k < L.n_all; k++) tab.push_back(tab[L.all_off - sh + k]); }
@@ -1390,13 +1402,17 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             enqueue_big_steps(c, L, s, [](int) {}, []() {});
         }
     }
-    if (mp) hipLaunchKernelGGL((k_backsolve_t<true>), dim3(mp_n), dim3(TPB), mp_dn_lds, s, c.dp, c.d_tab.p + mp_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + nFr, 1, c.d_bad.p, UpdArgs{});
+    if (mp && g_opt.wave_backsolve && mp_dn_maxns <= BSW_MAX_NS) hipLaunchKernelGGL(k_backsolve_w, dim3(mp_n), dim3(TPB), mp_dn_lds, s, c.dp, c.d_tab.p + mp_dn_off, c.d_pool.p, c.d_x.p, c.d_flags.p + nFr, c.d_bad.p, UpdArgs{});
+    else if (mp) hipLaunchKernelGGL((k_backsolve_t<true>), dim3(mp_n), dim3(TPB), mp_dn_lds, s, c.dp, c.d_tab.p + mp_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + nFr, 1, c.d_bad.p, UpdArgs{});
     for (int l = nLev - 1; l >= 0; l--) {
         if (mp && l >= 1) continue;
         if (batch) { launch_backsolve(c, dl[l], s, [](int) {}, []() {}); continue; }
         if (l >= I.nLev0 || needed) {
             if (bs_n[l] > 0) {
                 const size_t lds = l >= I.nLev0 ? solve_lds_of(nF0 + l - I.nLev0) : I.base_levels[l].solve_lds;
+                if (g_opt.wave_backsolve && bs_maxns[l] <= BSW_MAX_NS && bs_wlds[l] <= 160 * 1024)      // a few fronts per level: latency is all that counts
+                    hipLaunchKernelGGL(k_backsolve_w, dim3((unsigned)bs_n[l]), dim3(TPB), bs_wlds[l], s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, (int *)nullptr, (int *)nullptr, UpdArgs{});
+                else
                 hipLaunchKernelGGL((k_backsolve_t<false>), dim3((unsigned)bs_n[l]), dim3(TPB), lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr, UpdArgs{});
             }
         } else {                                     // every pose is visited: all base fronts, level by level
@@ -2463,6 +2479,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "persist") g_opt.persist = (int)v;
     else if (k == "persist_max_fronts") g_opt.persist_max_fronts = (int)v;
     else if (k == "linearize_staged_min") g_opt.linearize_staged_min = (int)v;
+    else if (k == "wave_backsolve") g_opt.wave_backsolve = (int)v;
     else if (k == "batch_extend") g_opt.batch_extend = (int)v;
     else if (k == "extend_tail_fronts") g_opt.extend_tail_fronts = (int)v;
     else return -1;

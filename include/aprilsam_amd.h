@@ -251,6 +251,9 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *                       per-front dependency flags; 0 = one launch per level
  *   "fused_panel"       0 = diagonal block and row solves of a multi-tile panel step as two kernels (default 1: one)
  *   "lookahead"         1 = wide trailing updates split, the far part on a side stream (default 0: measured no gain)
+ *   "wave_backsolve"    1 (default): fronts whose L panel fits LDS (multi-level launch, latency-bound levels, incremental
+ *                       steps) are back-substituted column-per-lane -- one in-register chain per 64 columns; 0 = the
+ *                       per-32-column-block kernel everywhere
  *   "linearize_staged_min"  graphs with at least this many factors (default 32768) write the J^T W J blocks out through
  *                       LDS with coalesced stores; smaller ones store directly (one latency chain less) */
 int aprilsam_amd_set_option(const char *name, double value);
