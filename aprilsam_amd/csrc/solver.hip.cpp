@@ -77,6 +77,7 @@ static void load_env_options() {
         v = g_opt.persist_max_fronts; envd("APRILSAM_AMD_PERSIST_MAX_FRONTS", &v); g_opt.persist_max_fronts = (int)v;
         v = g_opt.linearize_staged_min; envd("APRILSAM_AMD_LINEARIZE_STAGED_MIN", &v); g_opt.linearize_staged_min = (int)v;
         v = g_opt.wave_backsolve; envd("APRILSAM_AMD_WAVE_BACKSOLVE", &v); g_opt.wave_backsolve = (int)v;
+        v = g_opt.left_panels; envd("APRILSAM_AMD_LEFT_PANELS", &v); g_opt.left_panels = (int)v;
         v = g_opt.batch_extend; envd("APRILSAM_AMD_BATCH_EXTEND", &v); g_opt.batch_extend = (int)v;
         v = g_opt.extend_tail_fronts; envd("APRILSAM_AMD_EXTEND_TAIL_FRONTS", &v); g_opt.extend_tail_fronts = (int)v;
     });
@@ -589,9 +590,9 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     std::vector<int> wb;
     for (int sidx = 0; sidx < steps; sidx++) {
         const int nact = active(sidx);
-        L.panel.push_back(make(nact, [&](int t) { return panel_tiles(rows(t), 3 * nsb_of(t), sidx); }));
+        L.panel.push_back(make(nact, [&](int t) { return panel_tiles(rows(t), 3 * nsb_of(t), sidx, g_opt.left_panels && g_opt.fused_panel ? PANEL_ROWS_LL : PANEL_ROWS); }));
         L.diag_slot0.push_back(L.n_diag_slots);
-        if (!L.panel.back().single) {           // multi-tile step: the factored diagonal blocks wait in d_diag until the level's write-back
+        if (!L.panel.back().single || (g_opt.left_panels && g_opt.fused_panel)) {   // the factored diagonal blocks wait in d_diag until the level's write-back
             for (int i = 0; i < nact; i++) { wb.push_back(big[i]); wb.push_back(sidx); wb.push_back(L.n_diag_slots + i); }
             L.n_diag_slots += nact;
         }
@@ -811,7 +812,13 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
     hipEvent_t rest_done = nullptr;          // completion of the latest "rest" update on the side stream
     for (size_t k = 0; k < L.panel.size(); k++) {
         const Launch &pa = L.panel[k], &sy = L.syrk[k], &sw = L.syrkw[k];
-        if (pa.single) {          // one row tile per front: diagonal block + row solves in one launch
+        const bool ll = g_opt.left_panels && g_opt.fused_panel;       // left-looking panels: no narrow update launches
+        if (ll) {
+            tic(K_PANEL_BIG);
+            hipLaunchKernelGGL(k_diagpanel_ll, dim3(pa.grid), dim3(TPB), 0, s, c.dp, tab + pa.list_off, tab + pa.pre_off, pa.n, (int)k, c.d_pool.p,
+                               c.d_diag.p, L.diag_slot0[k], c.d_bad.p);
+            toc();
+        } else if (pa.single) {          // one row tile per front: diagonal block + row solves in one launch
             tic(K_PANEL_BIG);
             hipLaunchKernelGGL(k_diagpanel_big, dim3(pa.n), dim3(TPB), 0, s, c.dp, tab + pa.list_off, (int)k, c.d_pool.p, c.d_bad.p);
             toc();
@@ -828,7 +835,7 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
             hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, tab + pa.list_off, tab + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
             toc();
         }
-        if (sy.grid > 0) {
+        if (sy.grid > 0 && !ll) {
             tic(K_SYRK_BIG);
             hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, tab + sy.list_off, tab + sy.pre_off, sy.n, (int)k, (int)k + 1, 0, c.d_pool.p);
             toc();
@@ -2480,6 +2487,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "persist_max_fronts") g_opt.persist_max_fronts = (int)v;
     else if (k == "linearize_staged_min") g_opt.linearize_staged_min = (int)v;
     else if (k == "wave_backsolve") g_opt.wave_backsolve = (int)v;
+    else if (k == "left_panels") g_opt.left_panels = (int)v;
     else if (k == "batch_extend") g_opt.batch_extend = (int)v;
     else if (k == "extend_tail_fronts") g_opt.extend_tail_fronts = (int)v;
     else return -1;

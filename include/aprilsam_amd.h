@@ -251,6 +251,9 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *                       per-front dependency flags; 0 = one launch per level
  *   "fused_panel"       0 = diagonal block and row solves of a multi-tile panel step as two kernels (default 1: one)
  *   "lookahead"         1 = wide trailing updates split, the far part on a side stream (default 0: measured no gain)
+ *   "left_panels"       1 (default): inside a 128-column outer block of a multi-workgroup front every panel step applies the
+ *                       earlier panels' updates to its own 32 columns itself (MFMA, overlapped with the pivot chain) instead
+ *                       of a "narrow" update launch after every panel; 0 = right-looking narrow updates
  *   "wave_backsolve"    1 (default): fronts whose L panel fits LDS (multi-level launch, latency-bound levels, incremental
  *                       steps) are back-substituted column-per-lane -- one in-register chain per 64 columns; 0 = the
  *                       per-32-column-block kernel everywhere
