@@ -702,7 +702,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     if (g_opt.persist && !lay && P.nLevels >= 3) {
         int l0 = P.nLevels, cnt = 0;
         const int nt_top = c.levels[P.nLevels - 1].small_nt;
-        for (int l = P.nLevels - 1; l >= 1; l--) {
+        for (int l = P.nLevels - 1; l >= 0; l--) {           // (level 0 too when persist_max_fronts allows: small graphs run as one launch per sweep)
             const LevelPlan &L = c.levels[l];
             if (L.n_big > 0 || L.bs_gemv.grid > 0 || L.small_nt != nt_top || L.n_small != L.n_all || cnt + L.n_small > g_opt.persist_max_fronts) break;
             cnt += L.n_small; l0 = l;
