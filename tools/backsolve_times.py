@@ -1,4 +1,5 @@
-"""debug: per-level phase breakdown of k_backsolve (sets APRILSAM_AMD_KPROF=2): python tools/backsolve_times.py [--lattice K]"""
+"""debug: per-level phase breakdown of k_backsolve (sets APRILSAM_AMD_KPROF=2): python tools/backsolve_times.py [--lattice K]
+(gather = x of the struct rows in LDS; first products = up to the first block's barrier; rest = the remaining blocks / the chain)"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, "/root/repo")
@@ -19,4 +20,4 @@ for l in range(P.nLevels - 1, -1, -1):
     big = max(fr, key=lambda t: buf[t, 7] - buf[t, 4])
     b = buf[big] * 0.01
     span = (max(buf[t, 7] for t in fr) - min(buf[t, 4] for t in fr)) * 0.01
-    print(f"level {l}: span {span:.1f} | slowest nsb={P.front_nsb[big]} nub={P.front_nub[big]}: gather {b[5]-b[4]:.2f} first products {b[6]-b[5]:.2f} rest {b[7]-b[6]:.2f} total {b[7]-b[4]:.2f} | loop: products {b[8]:.2f} sums+barrier {b[9]:.2f} in-wave solve+barrier {b[10]:.2f}")
+    print(f"level {l}: span {span:.1f} | slowest nsb={P.front_nsb[big]} nub={P.front_nub[big]}: gather {b[5]-b[4]:.2f} first products {b[6]-b[5]:.2f} rest {b[7]-b[6]:.2f} total {b[7]-b[4]:.2f}")
