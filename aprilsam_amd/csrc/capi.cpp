@@ -9,6 +9,7 @@
 
 #include "../../include/aprilsam_amd.h"
 #include "plan.h"
+#include "errors.h"
 #include "refmodel.h"
 #include "solver.h"
 
@@ -112,6 +113,8 @@ void aprilsam_amd_refmodel_get(void *m, int *parent, int *changed, int *relin) {
     asam::RefModel *M = (asam::RefModel *)m;
     for (int i = 0; i < M->N; i++) { if (parent) parent[i] = M->parent[i]; if (changed) changed[i] = M->changed[i]; if (relin) relin[i] = M->relin[i]; }
 }
+int aprilsam_amd_last_error(char *msg, int cap) { return asam::get_last_error(msg, cap); }
+void aprilsam_amd_clear_error(void) { asam::clear_last_error(); }
 int aprilsam_amd_selftest(void) { return asam::selftest(); }
 const char *aprilsam_amd_version(void) { return "aprilsam_amd 0.1 (gfx950, multifrontal FP64)"; }
 void aprilsam_amd_free(void *p) { free(p); }
@@ -121,7 +124,14 @@ struct aprilsam_amd_plan { asam::Plan P; };
 
 aprilsam_amd_plan_t *aprilsam_amd_plan_create(int n_nodes, int n_factors, const int *factor_nodes, const double *xy, int leaf_nodes) {
     aprilsam_amd_plan *pl = new aprilsam_amd_plan();
-    asam::build_plan(pl->P, n_nodes, n_factors, factor_nodes, xy, leaf_nodes > 0 ? leaf_nodes : asam::g_opt.leaf_nodes);
+    try {
+        asam::build_plan(pl->P, n_nodes, n_factors, factor_nodes, xy, leaf_nodes > 0 ? leaf_nodes : asam::g_opt.leaf_nodes);
+    } catch (const asam::SolverError &e) {       // errors.h: NULL + aprilsam_amd_last_error
+        asam::set_last_error(e.code, e.msg);
+        fprintf(stderr, "aprilsam_amd: ERROR %d: %s\n", e.code, e.msg.c_str());
+        delete pl;
+        return nullptr;
+    }
     return pl;
 }
 void aprilsam_amd_plan_destroy(aprilsam_amd_plan_t *plan) { delete plan; }

@@ -7,7 +7,7 @@ namespace asam {
 
 struct Options {
     int leaf_nodes = 16;          // nested-dissection leaf size (pose nodes)
-    int deterministic = 1;        // 1: the wall-clock fallback rule aprilsam.c:557 is disabled
+    int deterministic = 0;        // 1: the wall-clock fallback rule aprilsam.c:557-559 is disabled (0 = the reference's behaviour)
     int use_graph = 1;            // replay the numeric phase from a captured hipGraph
     int device_timing = 0;        // record HIP events per stage (disables graph replay for that call)
     int trust_factor_cache = 0;   // 1: z/W of factors already packed are treated as immutable (skips the per-call content check)
@@ -29,6 +29,7 @@ struct Options {
     int linearize_staged_min = 32768; // factors per launch from which k_linearize writes its results out through LDS (coalesced stores)
     int fused_panel = 1;          // big fronts: diagonal block factored inside every row-tile workgroup of the panel kernel (0: k_diag_big + k_panel_big)
     int block_factor = 1;         // k_front_small: pivot chain of 16 columns at a time in registers (0: per 3x3 pivot through LDS)
+    int mem_cap_mb = 0;           // > 0: refuse any single device buffer above this size with ERR_OOM (tests: the out-of-memory path)
     int panel_mode = 1;           // fronts too large for LDS whose own columns fit run in k_front_small's panel mode
 };
 extern Options g_opt;

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/aprilsam_amd.h"
+#include "errors.h"
 #include "kernels.hip.h"
 #include "plan.h"
 #include "refmodel.h"
@@ -32,18 +33,20 @@ namespace asam {
 // ------------------------------------------------------------------------------------------------------
 // utilities
 // ------------------------------------------------------------------------------------------------------
+// The one failure that still ends the process: no GPU.  There is no CPU fallback to fall back to (see errors.h).
 [[noreturn]] static void fatal(const char *msg) {
     fprintf(stderr, "aprilsam_amd: FATAL: %s\n", msg);
     fflush(stderr);
     abort();
 }
+// every other failure is a SolverError caught at the entry point (guarded() below): states untouched, message on stderr,
+// code kept for aprilsam_amd_last_error / stats.error_code
 #define HIPCHECK(expr)                                                                                 \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
         if (e_ != hipSuccess) {                                                                        \
-            fprintf(stderr, "aprilsam_amd: FATAL: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            fflush(stderr);                                                                            \
-            abort();                                                                                   \
+            (void)hipGetLastError();                                                                   \
+            fail(e_ == hipErrorOutOfMemory ? ERR_OOM : ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
         }                                                                                              \
     } while (0)
 
@@ -80,6 +83,7 @@ static void load_env_options() {
         v = g_opt.left_panels; envd("APRILSAM_AMD_LEFT_PANELS", &v); g_opt.left_panels = (int)v;
         v = g_opt.batch_extend; envd("APRILSAM_AMD_BATCH_EXTEND", &v); g_opt.batch_extend = (int)v;
         v = g_opt.extend_tail_fronts; envd("APRILSAM_AMD_EXTEND_TAIL_FRONTS", &v); g_opt.extend_tail_fronts = (int)v;
+        v = g_opt.mem_cap_mb; envd("APRILSAM_AMD_MEM_CAP_MB", &v); g_opt.mem_cap_mb = (int)v;
     });
 }
 
@@ -104,14 +108,23 @@ static void ensure_device() {
     HIPCHECK(hipSetDevice(g_device));
 }
 
-// grow-only device / pinned-host buffers
+// grow-only device / pinned-host buffers.  A failed allocation leaves the buffer empty (never dangling) and throws ERR_OOM;
+// option mem_cap_mb (0 = off) refuses any single device buffer above that size the same way -- the tests use it to walk the
+// out-of-memory path without exhausting a 288 GB device.
 template <class T> struct DBuf {
     T *p = nullptr; size_t cap = 0;
     void need(size_t n) {
         if (n <= cap) return;
-        if (p) HIPCHECK(hipFree(p));
         size_t c = std::max(n, cap + cap / 2);
-        HIPCHECK(hipMalloc((void **)&p, c * sizeof(T)));
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }       // (freed first: the front pool of a large graph must not exist twice)
+        if (g_opt.mem_cap_mb > 0 && n * sizeof(T) > ((size_t)g_opt.mem_cap_mb << 20))
+            fail(ERR_OOM, "device buffer of %.1f MB refused: option mem_cap_mb = %d", (double)(n * sizeof(T)) / 1048576.0, g_opt.mem_cap_mb);
+        hipError_t e = hipMalloc((void **)&p, c * sizeof(T));
+        if (e != hipSuccess && c > n) { (void)hipGetLastError(); c = n; e = hipMalloc((void **)&p, c * sizeof(T)); }      // without the head-room
+        if (e != hipSuccess) {
+            (void)hipGetLastError(); p = nullptr;
+            fail(e == hipErrorOutOfMemory ? ERR_OOM : ERR_HIP, "hipMalloc of %.1f MB failed: %s", (double)(c * sizeof(T)) / 1048576.0, hipGetErrorString(e));
+        }
         cap = c;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -122,8 +135,12 @@ template <class T> struct HBuf {
         if (n <= cap) return;
         size_t c = std::max(n, cap + cap / 2);
         T *q = nullptr;
-        HIPCHECK(hipHostMalloc((void **)&q, c * sizeof(T), hipHostMallocDefault));
-        if (p) { if (keep) memcpy(q, p, cap * sizeof(T)); HIPCHECK(hipHostFree(p)); }
+        const hipError_t e = hipHostMalloc((void **)&q, c * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) {           // the old buffer stays valid
+            (void)hipGetLastError();
+            fail(e == hipErrorOutOfMemory ? ERR_OOM : ERR_HIP, "hipHostMalloc of %.1f MB failed: %s", (double)(c * sizeof(T)) / 1048576.0, hipGetErrorString(e));
+        }
+        if (p) { if (keep) memcpy(q, p, cap * sizeof(T)); (void)hipHostFree(p); }
         p = q; cap = c;
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
@@ -226,11 +243,11 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_ol
         else if ((f->nnodes == 1 || f->nnodes == 2) && f->eval) {     // any other type: the factor's own eval(), on the host
             *a = f->nodes[0]; *b = f->nnodes == 2 ? f->nodes[1] : -1; host_eval = true;
         } else {
-            fprintf(stderr, "aprilsam_amd: FATAL: factor %d has type %d / %d nodes; factors of foreign types are supported with one or "
-                            "two nodes and an eval() function pointer (aprilsam.h:110-122)\n", i, f->type, f->nnodes);
-            abort();
+            fail(ERR_UNSUPPORTED, "factor %d has type %d / %d nodes; factors of foreign types are supported with one or two nodes and an "
+                                  "eval() function pointer (aprilsam.h:110-122)", i, f->type, f->nnodes);
         }
-        if (*a < 0 || *a >= N || *b >= N || *a == *b) { fprintf(stderr, "aprilsam_amd: FATAL: factor %d references node out of range\n", i); abort(); }
+        if (*a < 0 || *a >= N || *b >= N) fail(ERR_BAD_GRAPH, "factor %d references node %d / %d of %d", i, *a, *b, N);
+        if (*a == *b) fail(ERR_BAD_GRAPH, "factor %d connects node %d to itself", i, *a);
         return host_eval;
     };
     if (from > 0 && !trust) {
@@ -309,7 +326,7 @@ static double eval_host_factors(GraphPack &gp, april_graph_t *g, int from) {
     for (int k = from; k < nh; k++) {
         april_graph_factor_t *f = fs[gp.host_idx[k]];
         april_graph_factor_eval_t *e = f->eval(f, g, nullptr);
-        if (!e || !e->jacobians || !e->jacobians[0] || !e->W || !e->r) fatal("factor->eval returned an incomplete evaluation (aprilsam.h:75-89)");
+        if (!e || !e->jacobians || !e->jacobians[0] || !e->W || !e->r) fail(ERR_BAD_GRAPH, "factor->eval returned an incomplete evaluation (aprilsam.h:75-89)");
         const int L = e->length;
         double *H = gp.h_hostH.p + (size_t)33 * k;
         memset(H, 0, 33 * 8);
@@ -317,12 +334,12 @@ static double eval_host_factors(GraphPack &gp, april_graph_t *g, int from) {
         for (int z0 = 0; z0 < f->nnodes; z0++) {
             const matd_t *J0 = e->jacobians[z0];
             if (!J0 || (int)J0->nrows != L || J0->ncols != 3 || (int)e->W->nrows != L || (int)e->W->ncols != L)
-                fatal("factor->eval: jacobians must be length x 3 and W length x length (3-DoF xyt nodes only, aprilsam.c:617)");
+                fail(ERR_UNSUPPORTED, "factor->eval: jacobians must be length x 3 and W length x length (3-DoF xyt nodes only, aprilsam.c:617)");
             for (int i = 0; i < 3; i++)
                 for (int l = 0; l < L; l++) { double acc = 0; for (int m = 0; m < L; m++) acc += J0->data[m * 3 + i] * e->W->data[m * L + l]; JtW[(size_t)i * L + l] = acc; }
             for (int z1 = z0; z1 < f->nnodes; z1++) {
                 const matd_t *J1 = e->jacobians[z1];
-                if (!J1) fatal("factor->eval: fewer jacobians than nodes");
+                if (!J1) fail(ERR_BAD_GRAPH, "factor->eval: fewer jacobians than nodes");
                 double *B = H + (z0 == 0 ? (z1 == 0 ? 0 : 9) : 18);
                 for (int i = 0; i < 3; i++)
                     for (int j = 0; j < 3; j++) { double acc = 0; for (int l = 0; l < L; l++) acc += JtW[(size_t)i * L + l] * J1->data[l * 3 + j]; B[i * 3 + j] = acc; }
@@ -351,7 +368,7 @@ static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp, boo
     for (int i = 0; i < N; i++) {
         if (i + 8 < N) __builtin_prefetch(ns[i + 8]->state);
         const april_graph_node_t *n = ns[i];
-        if (n->type != APRIL_GRAPH_NODE_XYT_TYPE || n->length != 3) fatal("only xyt nodes (type 100, 3 DoF) are supported (aprilsam.h:94)");
+        if (n->type != APRIL_GRAPH_NODE_XYT_TYPE || n->length != 3) fail(ERR_UNSUPPORTED, "node %d: only xyt nodes (type 100, 3 DoF) are supported (aprilsam.h:94)", i);
         memcpy(gp.h_state.p + (size_t)3 * i, n->state, 24);
         if (with_lp) memcpy(gp.h_lp.p + (size_t)3 * i, n->l_point, 24);
     }
@@ -446,7 +463,7 @@ struct Context {
     // incremental bookkeeping (aprilsam.c:741-751, 566-575)
     bool have_fact = false;               // a batch factorisation exists (reference: param->chol != NULL)
     int plan_pin = 0;                     // pin_last the plan was built with
-    int plan_persist = 0;                 // persist options the launch tables were built with
+    long long plan_persist = 0;           // launch_table_key() the launch tables were built with
     int same_topo_batches = 0;            // batch calls on an extended (base + tail fronts) plan whose topology did not change since the previous call
     bool used_inc = false;                // april_graph_cholesky_inc has been called on this param
     bool want_inc = false;                // the param has been used incrementally: plan uploads reserve the append slack
@@ -472,6 +489,7 @@ struct Context {
     int persist_l0 = -1;                  // first level of the multi-level launch, -1: none
     int p_up_off = 0, p_up_n = 0, p_dn_off = 0, p_dn_n = 0, p_nt = 1024; size_t p_up_lds = 0, p_dn_lds = 0; long long p_up_full = 0; int p_dn_maxns = 0;
     DBuf<int> d_flags, d_flevel, d_perm;
+    DBuf<int> d_solve_tab; std::vector<int> solve_tab;      // april_graph_cholesky_inc_solver: front lists of its back substitution
     hipGraphExec_t gexec = nullptr;
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
     // the same phase as the API call runs it: first kernel reads the caller's states from the pinned mirror, last kernel
@@ -481,7 +499,7 @@ struct Context {
     double lambda_val = -1; int lambda_N = -1;     // what d_lambda currently holds (uniform batch value), -1: unknown
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
-        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release(); d_flags.release(); d_flevel.release(); d_perm.release();
+        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release(); d_flags.release(); d_flevel.release(); d_perm.release(); d_solve_tab.release();
         if (gexec) (void)hipGraphExecDestroy(gexec);
         gexec = nullptr;
         if (gexec_api) (void)hipGraphExecDestroy(gexec_api);
@@ -514,6 +532,61 @@ bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out)
     if (it == g_ctx.end()) return false;
     *out = it->second->st;
     return true;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// failure path (errors.h): every entry point below runs its body inside guarded().  A SolverError thrown anywhere under
+// it unwinds to here (the body's lock_guard is released on the way): message on stderr, code kept for
+// aprilsam_amd_last_error / stats.error_code, and the solver state that may be half-built -- the graph's pack, the param's
+// plan, fronts, captured graphs, sharding state -- is dropped wholesale, exactly as param_destory / graph_destroy would.
+// The caller's node objects are only ever written after a call's final stream sync succeeded, so they are untouched.
+// ------------------------------------------------------------------------------------------------------
+struct ShardState;
+static void drop_shard_state(const void *param);
+static void on_failure(const april_graph_cholesky_param_t *param, const april_graph_t *g, int code, const std::string &msg) {
+    set_last_error(code, msg);
+    fprintf(stderr, "aprilsam_amd: ERROR %d: %s -- node states left untouched\n", code, msg.c_str());
+    fflush(stderr);
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipGetLastError();
+    if (g) {
+        auto it = g_packs.find(g);
+        if (it != g_packs.end()) {
+            hipStream_t s = it->second->stream;
+            if (s) {
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {      // failed inside a capture
+                    hipGraph_t gr = nullptr;
+                    (void)hipStreamEndCapture(s, &gr);
+                    if (gr) (void)hipGraphDestroy(gr);
+                }
+                (void)hipStreamSynchronize(s);           // whatever was enqueued before the failure
+                (void)hipGetLastError();
+            }
+            it->second->release(); g_packs.erase(it);
+        }
+    }
+    if (param) {
+        drop_shard_state(param);
+        auto it = g_ctx.find(param);
+        aprilsam_amd_stats_t st{};
+        if (it != g_ctx.end()) { st = it->second->st; it->second->release(); }
+        auto fresh = std::make_unique<Context>();
+        fresh->st = st; fresh->st.error_code = code; fresh->st.not_spd = 0;
+        g_ctx[param] = std::move(fresh);
+    }
+}
+template <class Fn> static void guarded(const april_graph_cholesky_param_t *param, const april_graph_t *g, Fn &&fn) {
+    try { fn(); }
+    catch (const SolverError &e) { on_failure(param, g, e.code, e.msg); }
+    catch (const std::bad_alloc &) { on_failure(param, g, ERR_OOM, "host memory exhausted (std::bad_alloc)"); }
+    catch (const std::exception &e) { on_failure(param, g, ERR_INTERNAL, e.what()); }
+}
+template <class Fn> static int guarded_rc(const april_graph_cholesky_param_t *param, const april_graph_t *g, Fn &&fn) {
+    try { return fn(); }
+    catch (const SolverError &e) { on_failure(param, g, e.code, e.msg); return e.code; }
+    catch (const std::bad_alloc &) { on_failure(param, g, ERR_OOM, "host memory exhausted (std::bad_alloc)"); return ERR_OOM; }
+    catch (const std::exception &e) { on_failure(param, g, ERR_INTERNAL, e.what()); return ERR_INTERNAL; }
 }
 
 // slack reserved at plan upload so that the incremental path can append without reallocating device buffers
@@ -695,8 +768,8 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     }
     for (int l = 0; l < P.nLevels; l++)
         if (c.levels[l].solve_lds > 160 * 1024)       // k_backsolve keeps x over a front's rows in LDS (~19 000 scalar rows)
-            fatal("a frontal matrix has more rows than the back-substitution kernel can hold in LDS (an unsplittable dense region "
-                  "of more than ~6000 poses); this build does not tile the solve of such a front");
+            fail(ERR_UNSUPPORTED, "a frontal matrix has more rows than the back-substitution kernel can hold in LDS (an unsplittable dense region "
+                 "of more than ~6000 poses); this build does not tile the solve of such a front");
     // ---- multi-level launch over the top of the tree (small fronts only, few per level) ------------------------------
     c.persist_l0 = -1;
     if (g_opt.persist && !lay && P.nLevels >= 3) {
@@ -1007,18 +1080,23 @@ static double device_chi2(GraphPack &gp) {     // chi^2 at d_state; synchronises
     return gp.h_scalar.p[0];
 }
 
+// Options are baked into the launch tables at plan time (build_level: small / panel / big classification, tile counts,
+// diagonal-block slots) AND read again when the kernels are enqueued or captured into a hipGraph.  Every change of an option
+// that touches either (api_set_option bumps g_opt_epoch) therefore forces a re-plan and a re-capture on every param.
+static long long g_opt_epoch = 0;
+static long long launch_table_key() { return g_opt_epoch; }
 // make sure plan / device buffers match the packed graph; returns true if the plan was reused
 static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g, bool upload = true) {
     const int N = gp.N, F = gp.F;
     bool same = c.have_plan && c.patN == N && (int)c.pat.size() == 2 * F && c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last &&
-                c.plan_persist == g_opt.persist * 100000 + g_opt.persist_max_fronts && c.inc.t_first.empty();        // (a plan extended by tail fronts is only driven by inc_fast_step)
+                c.plan_persist == launch_table_key() && c.inc.t_first.empty();        // (a plan extended by tail fronts is only driven by inc_fast_step)
     if (same) {
         for (int i = 0; i < F && same; i++) same = c.pat[2 * i] == gp.h_fa.p[i] && c.pat[2 * i + 1] == gp.h_fb.p[i];
     }
     if (same) return true;
     c.pat.resize((size_t)2 * F);
     for (int i = 0; i < F; i++) { c.pat[2 * i] = gp.h_fa.p[i]; c.pat[2 * i + 1] = gp.h_fb.p[i]; }
-    c.patN = N; c.plan_pin = g_opt.pin_last; c.plan_persist = g_opt.persist * 100000 + g_opt.persist_max_fronts;
+    c.patN = N; c.plan_pin = g_opt.pin_last; c.plan_persist = launch_table_key();
     std::vector<double> xy((size_t)2 * N);
     for (int i = 0; i < N; i++) { xy[2 * i] = gp.h_state.p[3 * i]; xy[2 * i + 1] = gp.h_state.p[3 * i + 1]; }
     const double tb0 = now_ms();
@@ -1439,6 +1517,16 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     return true;
 }
 
+// After a synchronised numeric phase: c.h_bad mirrors the device's failure record {flag, front, kind, step}.  kind 9 = a
+// dependency-flag poll of a multi-level launch gave up (wait_flag): that is a failure of the launch, not of the matrix, and
+// is reported as ERR_DEP_TIMEOUT; everything else is a non-positive pivot (returns true, stats.not_spd).
+static bool check_bad(Context &c) {
+    if (!c.h_bad.p[0]) { c.st.not_spd = 0; return false; }
+    if (c.h_bad.p[0] == 9 || c.h_bad.p[2] == 9) fail(ERR_DEP_TIMEOUT, "a multi-level launch gave up waiting for a dependency flag (the fronts it waits for never finished)");
+    c.st.not_spd = 1;
+    return true;
+}
+
 static void set_lambda(Context &c, GraphPack &gp, double lambda) {
     const int N = c.plan.N;
     if (c.lambda_N == N && c.lambda_val == lambda) return;       // d_lambda already holds it (warm calls)
@@ -1475,14 +1563,17 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     {
         const int patF = (int)c.pat.size() / 2;
         bool ext = g_opt.batch_extend && !timing && c.have_plan && c.inc.ready && gp.host_idx.empty() && N >= c.patN && F >= patF &&
-                   c.inc_N == c.patN && c.inc_F == patF && c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last;
+                   c.inc_N == c.patN && c.inc_F == patF && c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last &&
+                   c.plan_persist == launch_table_key();
         for (int i = 0; i < patF && ext; i++) ext = c.pat[2 * i] == gp.h_fa.p[i] && c.pat[2 * i + 1] == gp.h_fb.p[i];
         const bool grew = ext && (N > c.patN || F > patF);
         if (grew) { c.want_inc = true; c.same_topo_batches = 0; }        // (plans made from now on reserve the append slack)
         else if (ext && !c.inc.t_first.empty()) c.same_topo_batches++;
         const int tails_after = (N - c.inc.Nb + TAIL_POSES - 1) / TAIL_POSES;
         if (ext && N > c.inc.Nb && c.inc.cap_nodes > 0 && tails_after <= g_opt.extend_tail_fronts && (grew || (!c.inc.t_first.empty() && c.same_topo_batches <= 1))) {
-            if (F > gp.F_cap) upload_factors(gp);
+            // z / W of already-packed factors edited in place by the caller (pack_factors recorded the range) only reach the
+            // device through upload_factors: the patch list of inc_fast_step carries the NEW factors alone
+            if (F > gp.F_cap || gp.dirty_hi > gp.dirty_lo) upload_factors(gp);
             c.h_bad.need(4);
             hybrid = inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, nullptr, param->tikhanov > 0 ? param->tikhanov : 0.0);
             reused = hybrid;
@@ -1498,6 +1589,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         // One graph launch: k_load_states pulls the packed states from the pinned mirror (state and, every node being
         // re-linearised first, aprilsam.c:131-135, l_point), ..., k_update_states leaves new states (h_lp), dx and the pivot
         // flag in pinned mirrors.  No copy-engine call on the path.
+        c.h_bad.p[0] = c.h_bad.p[1] = c.h_bad.p[2] = c.h_bad.p[3] = 0;          // (the kernels only ever write a SET failure record)
         run_numeric(c, gp, timing, false, true);
     }
     // while the GPU works: a param that is used incrementally needs the reference's elimination tree of THIS batch step for
@@ -1506,7 +1598,8 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (c.used_inc && gp.host_idx.empty()) { c.model.batch(N, F, gp.h_fa.p, gp.h_fb.p); model_ready = true; }      // (not for params that only ever see batch calls)
     HIPCHECK(hipStreamSynchronize(gp.stream));
     const double t4 = now_ms();
-    c.st.not_spd = c.h_bad.p[0] != 0;
+    check_bad(c);
+    c.st.error_code = 0;
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
     if (c.st.not_spd) {
         c.model.valid = false;
@@ -1559,10 +1652,12 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
 
 void batch_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0) return;          // aprilsam.c:90-91
-    if (!param->nreordering) fatal("april_graph_cholesky: param->nreordering == 0 (the reference asserts, aprilsam.c:372-374)");
-    ensure_device();
-    std::lock_guard<std::mutex> lk(g_mu);
-    batch_impl(g, param);
+    guarded(param, g, [&] {
+        if (!param->nreordering) fail(ERR_UNSUPPORTED, "april_graph_cholesky: param->nreordering == 0 (the reference asserts, aprilsam.c:372-374)");
+        ensure_device();
+        std::lock_guard<std::mutex> lk(g_mu);
+        batch_impl(g, param);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1585,8 +1680,13 @@ struct IncProf {
 };
 static IncProf g_incprof;
 
+static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param);
+static void apply_visits(Context &c, GraphPack &gp, april_graph_t *g, april_graph_cholesky_param_t *param, int N);
 void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0) return;          // aprilsam.c:380-381
+    guarded(param, g, [&] { inc_impl(g, param); });
+}
+static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     std::lock_guard<std::mutex> lk(g_mu);
     {
         auto it = g_ctx.find(param);
@@ -1637,11 +1737,12 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (!reused) {                // (the fast path's last kernel wrote states, dx and the pivot flag into the pinned mirrors itself)
         HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
         HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
-        HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, gp.stream));
+        HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 16, hipMemcpyDeviceToHost, gp.stream));
     }
     HIPCHECK(hipStreamSynchronize(gp.stream));
     const double tp5 = now_ms();
-    c.st.not_spd = c.h_bad.p[0] != 0;
+    check_bad(c);
+    c.st.error_code = 0;
     c.st.n_nodes = N; c.st.n_factors = F; c.st.symbolic_reused = reused;
     if (c.st.not_spd) {
         static bool warned = false;
@@ -1651,17 +1752,7 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     // bookkeeping exactly as the reference: which poses solve_node visits / updates, start_over (refmodel.cpp)
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
     for (int i = 0; i < N; i++) ns[i]->UID = i;                          // aprilsam.c:474
-    const double *x = gp.h_dx.p;                                          // dx per node; NaN where the solve produced NaN
-    c.model.count_relinearized(x, param->delta_xy, param->delta_theta, visits);
-    for (const RefModel::Visit &vis : visits) {
-        const int n = vis.node; const bool update = vis.update;
-        april_graph_node_t *nd = ns[n];
-        const double *dx = x + (size_t)3 * n;
-        memcpy(nd->delta_X, dx, 24);                                      // aprilsam.c:752-754
-        if (!update) continue;
-        if (std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2])) continue;   // april_graph_xyt.c:304-305
-        memcpy(nd->state, gp.h_state.p + (size_t)3 * n, 24);              // l_point + dx, theta wrapped (k_update_states)
-    }
+    apply_visits(c, gp, g, param, N);
     if (param->ordering) free(param->ordering);
     param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
     memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
@@ -1669,6 +1760,10 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     param->factor_num = F;
     const double step_ms = now_ms() - t0;
     c.st.ms_total = step_ms;
+    if (param->show_timing)
+        printf("aprilsam_amd inc: N=%d F=%d fronts=%d (%d regenerated) marked=%d visited=%zu%s | pack %.3f model %.3f plan+enqueue %.3f device %.3f | total %.3f ms\n",
+               N, F, c.st.n_fronts, reused ? c.st.reserved0 : c.st.n_fronts, c.model.naffected, c.visits.size(), reused ? "" : " (re-planned)",
+               tp1 - t0, tp2 - tp1, tp4 - tp3, tp5 - tp4, step_ms);
     if (g_incprof.on) {
         g_incprof.acc[0] += tp1 - t0; g_incprof.acc[1] += tp2 - tp1; g_incprof.acc[2] += tp3 - tp2; g_incprof.acc[3] += tp4 - tp3;
         g_incprof.acc[4] += tp5 - tp4; g_incprof.acc[5] += now_ms() - tp5; g_incprof.n++;
@@ -1681,38 +1776,118 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     }
 }
 
-// aprilsam.c:578-597: back-substitution + state update on the current factorisation
-void inc_solve_only(april_graph_t *g, april_graph_cholesky_param_t *param) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_ctx.find(param);
-    if (it == g_ctx.end() || !it->second->have_fact || !param->nreordering) return;
-    ensure_device();
-    Context &c = *it->second;
-    GraphPack &gp = pack_for(g);
-    const Plan &P = c.plan;
-    const int N = P.N;
-    if (gp.N != N) return;
-    hipStream_t s = gp.stream;
-    set_small_attr();
-    for (int l = P.nLevels - 1; l >= 0; l--) {
-        const LevelPlan &L = c.levels[l];
-        hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr, UpdArgs{});
+// Back substitution over the CURRENT structures of a param (base plan of the last batch step + tail fronts appended since),
+// restricted to the fronts that hold a pose of `needed` and their ancestors (null: every front).  Used by
+// april_graph_cholesky_inc_solver; april_graph_cholesky_inc has the same loop inside inc_fast_step, fed by its patch list.
+static void enqueue_backsolve_current(Context &c, GraphPack &gp, const std::vector<RefModel::Visit> *needed) {
+    IncState &I = c.inc; const Plan &P = c.plan;
+    const int nF0 = I.nF0, nT = (int)I.t_first.size(), nFr = nF0 + nT, nLev = I.nLev0 + nT, Nb = I.Nb;
+    I.need.assign(nFr, needed ? 0 : 1);
+    if (needed)
+        for (const RefModel::Visit &v : *needed) {
+            int t = v.node >= Nb ? I.tf_of[v.node - Nb] : I.pos_front[P.pos[v.node]];
+            while (t >= 0 && !I.need[t]) { I.need[t] = 1; t = I.parent[t]; }
+        }
+    std::vector<int> &tab = c.solve_tab; tab.clear();
+    std::vector<int> off(nLev + 1, 0);
+    {
+        std::vector<int> cnt(nLev, 0);
+        for (int t = 0; t < nFr; t++) if (I.need[t]) cnt[I.f_level[t]]++;
+        for (int l = 0; l < nLev; l++) off[l + 1] = off[l] + cnt[l];
+        tab.resize(std::max(1, off[nLev]));
+        std::vector<int> fill(off.begin(), off.end() - 1);
+        for (int t = 0; t < nFr; t++) if (I.need[t]) tab[fill[I.f_level[t]]++] = t;
     }
-    hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p);
-    HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
-    HIPCHECK(hipStreamSynchronize(s));
-    april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
-    for (int i = 0; i < N && i < zsize(g->nodes); i++) {
-        const double *dx = gp.h_dx.p + (size_t)3 * i;
-        if (std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2])) continue;
-        memcpy(ns[i]->state, gp.h_state.p + (size_t)3 * i, 24);
-        memcpy(ns[i]->delta_X, dx, 24);
+    c.d_solve_tab.need(tab.size());
+    hipStream_t s = gp.stream;
+    HIPCHECK(hipMemcpyAsync(c.d_solve_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));      // (c.solve_tab lives until the caller's sync)
+    for (int l = nLev - 1; l >= 0; l--) {
+        const int n = off[l + 1] - off[l];
+        if (!n) continue;
+        int maxns = 0; size_t wlds = 0, tlds = 0;
+        for (int k = off[l]; k < off[l + 1]; k++) {
+            const FrontDesc &D = I.fd[tab[k]];
+            const int ns = 3 * D.nsb, m = 3 * (D.nsb + D.nub);
+            maxns = std::max(maxns, ns); wlds = std::max(wlds, backsolve_lds(m, ns, true));
+            tlds = std::max(tlds, (size_t)(m + NB + 8 + NB * (NB + 1)) * 8);
+        }
+        if (g_opt.wave_backsolve && maxns <= BSW_MAX_NS && wlds <= 160 * 1024)
+            hipLaunchKernelGGL(k_backsolve_w, dim3((unsigned)n), dim3(TPB), wlds, s, c.dp, c.d_solve_tab.p + off[l], c.d_pool.p, c.d_x.p, (int *)nullptr, (int *)nullptr, UpdArgs{});
+        else
+            hipLaunchKernelGGL((k_backsolve_t<false>), dim3((unsigned)n), dim3(TPB), tlds, s, c.dp, c.d_solve_tab.p + off[l], c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr, UpdArgs{});
     }
 }
 
+// After the numbers arrived (gp.h_dx / gp.h_state hold dx and l_point + dx of every pose the back substitution reached):
+// the reference's bookkeeping, aprilsam.c:741-775 -- relinearisation counter over the visited poses, delta_X of every visited
+// pose, state of the updated ones (NaN guard april_graph_xyt.c:304-305) -- and param->delta_x, which the reference only
+// keeps when the caller pre-allocated it (aprilsam.c:590-595; x is a fresh zero vector per call, :583, so poses the walk did
+// not reach read 0; indexed like the unknowns: 3 * position in param->ordering).
+static void apply_visits(Context &c, GraphPack &gp, april_graph_t *g, april_graph_cholesky_param_t *param, int N) {
+    april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
+    const double *x = gp.h_dx.p;                                          // dx per node; NaN where the solve produced NaN
+    c.model.count_relinearized(x, param->delta_xy, param->delta_theta, c.visits);
+    for (const RefModel::Visit &vis : c.visits) {
+        const int n = vis.node; const bool update = vis.update;
+        april_graph_node_t *nd = ns[n];
+        const double *dx = x + (size_t)3 * n;
+        memcpy(nd->delta_X, dx, 24);                                      // aprilsam.c:752-754
+        if (!update) continue;
+        if (std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2])) continue;   // april_graph_xyt.c:304-305
+        memcpy(nd->state, gp.h_state.p + (size_t)3 * n, 24);              // l_point + dx, theta wrapped (k_update_states)
+    }
+    if (param->delta_x) {
+        free(param->delta_x);
+        param->delta_x = (double *)calloc((size_t)3 * N, sizeof(double));
+        for (const RefModel::Visit &vis : c.visits) memcpy(param->delta_x + (size_t)3 * c.plan.pos[vis.node], x + (size_t)3 * vis.node, 24);
+    }
+}
+
+// aprilsam.c:578-597: back substitution + state update on the current factorisation, with solve_node's visit rule
+// (aprilsam.c:721-779: after the last april_graph_cholesky_inc marked more than 5 poses the whole tree is walked and every
+// pose gets state = l_point + x -- the caller's CURRENT l_points, april_graph_xyt.c:307-308; otherwise only the root is
+// reached and only its delta_X is written).  y persists inside the fronts (the right-hand-side row), so x is reproducible.
+void inc_solve_only(april_graph_t *g, april_graph_cholesky_param_t *param) {
+    if (zsize(g->nodes) == 0) return;
+    guarded(param, g, [&] {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_ctx.find(param);
+        if (it == g_ctx.end() || !it->second->have_fact || !param->nreordering) return;        // aprilsam.c:580
+        ensure_device();
+        Context &c = *it->second;
+        GraphPack &gp = pack_for(g);
+        const int N = c.inc_N;
+        // poses added since the factorisation was made are april_graph_cholesky_inc's business (the reference would read past
+        // the end of its factor here)
+        if (!c.inc.ready || zsize(g->nodes) != N || gp.N != N) return;
+        const double t0 = now_ms();
+        pack_states(gp, g, true, false);
+        c.h_bad.need(4);
+        if (!c.model.valid) c.model.batch(c.batch_nodes, c.batch_factors, gp.h_fa.p, gp.h_fb.p);
+        c.model.plan_visit(c.visits);
+        const bool partial = c.model.naffected <= 5;
+        hipStream_t s = gp.stream;
+        set_small_attr();
+        hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
+        enqueue_backsolve_current(c, gp, partial ? &c.visits : nullptr);
+        hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
+                           gp.h_state.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipStreamSynchronize(s));
+        apply_visits(c, gp, g, param, N);
+        c.st.error_code = 0; c.st.ms_total = now_ms() - t0;
+        if (param->show_timing) printf("aprilsam_amd solve: N=%d visited %zu poses%s | total %.3f ms\n", N, c.visits.size(), partial ? " (marked root paths only)" : "", c.st.ms_total);
+    });
+}
+
+static double chi2_impl(april_graph_t *g);
 double graph_chi2(april_graph_t *g) {
     if (zsize(g->factors) == 0) return 0;
+    double out = std::nan("");                        // a failed evaluation (errors.h) returns NaN
+    guarded(nullptr, g, [&] { out = chi2_impl(g); });
+    return out;
+}
+static double chi2_impl(april_graph_t *g) {
     ensure_device();
     std::lock_guard<std::mutex> lk(g_mu);
     GraphPack &gp = pack_for(g);
@@ -1734,7 +1909,9 @@ double graph_chi2(april_graph_t *g) {
 // ------------------------------------------------------------------------------------------------------
 // device-resident driver API: states never leave HBM between Gauss-Newton steps
 // ------------------------------------------------------------------------------------------------------
-int resident_begin(april_graph_t *g, april_graph_cholesky_param_t *param) {
+static int resident_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *param);
+int resident_begin(april_graph_t *g, april_graph_cholesky_param_t *param) { return guarded_rc(param, g, [&] { return resident_begin_impl(g, param); }); }
+static int resident_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0) return -1;
     ensure_device();
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1754,7 +1931,9 @@ int resident_begin(april_graph_t *g, april_graph_cholesky_param_t *param) {
 }
 // enqueue n iterations.  mode 0: asynchronous (hipGraph replay when enabled), returns at once;
 // mode 1: every kernel bracketed by HIP events on the solver stream, synchronises after each iteration.
-int resident_steps(april_graph_t *g, april_graph_cholesky_param_t *param, int n, int mode) {
+static int resident_steps_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int n, int mode);
+int resident_steps(april_graph_t *g, april_graph_cholesky_param_t *param, int n, int mode) { return guarded_rc(param, g, [&] { return resident_steps_impl(g, param, n, mode); }); }
+static int resident_steps_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int n, int mode) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_ctx.find(param);
     if (it == g_ctx.end() || !it->second->have_plan) return -1;
@@ -1776,7 +1955,9 @@ int resident_steps(april_graph_t *g, april_graph_cholesky_param_t *param, int n,
     }
     return 0;
 }
-int resident_sync(april_graph_t *g, april_graph_cholesky_param_t *param) {
+static int resident_sync_impl(april_graph_t *g, april_graph_cholesky_param_t *param);
+int resident_sync(april_graph_t *g, april_graph_cholesky_param_t *param) { return guarded_rc(param, g, [&] { return resident_sync_impl(g, param); }); }
+static int resident_sync_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_ctx.find(param);
     if (it == g_ctx.end()) return -1;
@@ -1784,7 +1965,7 @@ int resident_sync(april_graph_t *g, april_graph_cholesky_param_t *param) {
     GraphPack &gp = pack_for(g);
     HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 16, hipMemcpyDeviceToHost, gp.stream));
     HIPCHECK(hipStreamSynchronize(gp.stream));
-    c.st.not_spd = c.h_bad.p[0] != 0;
+    check_bad(c);
     if (c.h_bad.p[0] && getenv("APRILSAM_AMD_DEBUG")) {
         const int t = c.h_bad.p[1];
         fprintf(stderr, "aprilsam_amd: bad pivot: front %d kernel %d step %d", t, c.h_bad.p[2], c.h_bad.p[3]);
@@ -1793,11 +1974,19 @@ int resident_sync(april_graph_t *g, april_graph_cholesky_param_t *param) {
     }
     return c.h_bad.p[0] ? -2 : 0;
 }
+static double resident_chi2_impl(april_graph_t *g);
 double resident_chi2(april_graph_t *g) {
+    double out = std::nan("");
+    guarded(nullptr, g, [&] { out = resident_chi2_impl(g); });
+    return out;
+}
+static double resident_chi2_impl(april_graph_t *g) {
     std::lock_guard<std::mutex> lk(g_mu);
     return device_chi2(pack_for(g));
 }
-int resident_end(april_graph_t *g, april_graph_cholesky_param_t *param) {
+static int resident_end_impl(april_graph_t *g, april_graph_cholesky_param_t *param);
+int resident_end(april_graph_t *g, april_graph_cholesky_param_t *param) { return guarded_rc(param, g, [&] { return resident_end_impl(g, param); }); }
+static int resident_end_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_ctx.find(param);
     if (it == g_ctx.end()) return -1;
@@ -1881,7 +2070,9 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
 // what = 1: the assembled normal equations A = sum J^T W J + lambda I (dense symmetric (3N)^2, row-major) and
 //           B = sum J^T W r (3N) in NODE coordinates, from the per-destination sums of the assembly's own source lists
 //           (out: 9 N^2 + 3 N doubles; N <= 2000)
-int debug_stage(april_graph_t *g, april_graph_cholesky_param_t *param, int what, double *out) {
+static int debug_stage_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int what, double *out);
+int debug_stage(april_graph_t *g, april_graph_cholesky_param_t *param, int what, double *out) { return guarded_rc(param, g, [&] { return debug_stage_impl(g, param, what, out); }); }
+static int debug_stage_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int what, double *out) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0) return -1;
     ensure_device();
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1967,8 +2158,8 @@ int debug_front_times(const april_graph_cholesky_param_t *param, long long *out,
 //   * up:   the Schur update block of a front whose parent lives on another rank (the lower trapezoid of columns
 //           3*nsb.. end of its frontal array, packed by k_pack_update), sent point-to-point to the parent's owner,
 //   * down: the solved x of the "top" fronts (range > 1 rank), a few thousand doubles each, broadcast.
-// The library only provides the per-level compute steps and the slab copies; the exchange itself is done by the
-// host driver with RCCL through torch.distributed (aprilsam_amd/shard.py) — one process per GPU.
+// The exchange happens inside the library (shard_iterate), over one of the two transports below; aprilsam_amd/shard.py
+// is only a launcher (one process per GPU) that hands the RCCL unique id / the host callbacks over.
 // ------------------------------------------------------------------------------------------------------
 // ---- transports -----------------------------------------------------------------------------------------------
 // RCCL (librccl.so, loaded at run time: point-to-point send / recv of the Schur slabs, broadcast of the separator
@@ -2067,6 +2258,10 @@ struct ShardState {
     void release() { d_tab.release(); d_flist.release(); d_nown.release(); d_send.release(); d_recv.release(); d_scratch.release(); tr.reset(); }
 };
 static std::unordered_map<const void *, std::unique_ptr<ShardState>> g_shard;
+static void drop_shard_state(const void *param) {           // (failure path; g_mu held)
+    auto it = g_shard.find(param);
+    if (it != g_shard.end()) { it->second->release(); g_shard.erase(it); }
+}
 
 // Ownership of the fronts and the exchange lists of a `world`-rank run: pure host logic on the plan (also reachable
 // without a GPU through aprilsam_amd_shard_plan, tests/test_distributed_cpu.py)
@@ -2118,7 +2313,9 @@ void shard_map(const Plan &P, int world, std::vector<int> &owner, std::vector<ch
 // Every rank calls this with the same graph.  Builds the (identical) plan, the ownership map, THIS rank's pool layout
 // (owned fronts + ghosts), launch tables and exchange buffers.  A transport must be attached before the first
 // iteration unless world == 1 (shard_comm_init_rccl / shard_comm_init_host).
-int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank, int world) {
+static int shard_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int rank, int world);
+int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank, int world) { return guarded_rc(param, g, [&] { return shard_begin_impl(g, param, rank, world); }); }
+static int shard_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int rank, int world) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0 || world < 1 || rank < 0 || rank >= world) return -1;
     ensure_device();
     std::lock_guard<std::mutex> lk(g_mu);
@@ -2220,7 +2417,9 @@ int shard_comm_unique_id(char *out128) {
     memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
     return 0;
 }
-int shard_comm_init_rccl(const april_graph_cholesky_param_t *param, const char *id128) {
+static int shard_comm_init_rccl_impl(const april_graph_cholesky_param_t *param, const char *id128);
+int shard_comm_init_rccl(const april_graph_cholesky_param_t *param, const char *id128) { return guarded_rc(param, nullptr, [&] { return shard_comm_init_rccl_impl(param, id128); }); }
+static int shard_comm_init_rccl_impl(const april_graph_cholesky_param_t *param, const char *id128) {
     ensure_device();
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_shard.find(param);
@@ -2248,7 +2447,9 @@ int shard_comm_init_host(const april_graph_cholesky_param_t *param, const aprils
 
 // n Gauss-Newton iterations of the sharded solve: per level the owned fronts, then the Schur slabs whose parent lives on
 // another rank (packed lower trapezoid, point to point); on the way down the solved x of the top fronts (broadcast).
-int shard_iterate(april_graph_t *g, april_graph_cholesky_param_t *param, int n) {
+static int shard_iterate_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int n);
+int shard_iterate(april_graph_t *g, april_graph_cholesky_param_t *param, int n) { return guarded_rc(param, g, [&] { return shard_iterate_impl(g, param, n); }); }
+static int shard_iterate_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int n) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_shard.find(param); auto ic = g_ctx.find(param);
     if (it == g_shard.end() || ic == g_ctx.end()) return -1;
@@ -2262,9 +2463,9 @@ int shard_iterate(april_graph_t *g, april_graph_cholesky_param_t *param, int n) 
     const int N = gp.N, me = S.rank;
     auto nop = [](int) {}; auto nop0 = []() {};
     Transport *T = S.tr.get();
+    HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 16, s));          // sticky over the n iterations: the first failure is the one reported
     for (int iter = 0; iter < n; iter++) {
         HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));      // relinearise
-        HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 16, s));
         if (S.n_flist)
             hipLaunchKernelGGL((k_linearize_t<false>), dim3((S.n_flist + TPB - 1) / TPB), dim3(TPB), 0, s, 0, S.n_flist, (const int *)S.d_flist.p, gp.d_fa.p, gp.d_fb.p,
                                gp.d_z.p, gp.d_W.p, gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, (int *)nullptr, (const double *)nullptr);
@@ -2305,17 +2506,34 @@ int shard_iterate(april_graph_t *g, april_graph_cholesky_param_t *param, int n) 
         HIPCHECK(hipGetLastError());
         if (T && T->failed) break;
     }
-    HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 16, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     if (T && T->failed) return -6;
-    c.st.not_spd = c.h_bad.p[0] != 0;
-    return c.h_bad.p[0] ? -2 : 0;
+    // a pivot fails on ONE rank (the owner of the front); every rank must leave with the same answer, or the others walk
+    // into the next collective alone: the flags are added up over the transport
+    double flag = c.h_bad.p[0] ? ((c.h_bad.p[0] == 9 || c.h_bad.p[2] == 9) ? 1e6 : 1.0) : 0.0;
+    if (T) {
+        gp.d_scalar.need(8); gp.h_scalar.need(8);
+        gp.h_scalar.p[0] = flag;
+        HIPCHECK(hipMemcpyAsync(gp.d_scalar.p, gp.h_scalar.p, 8, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        T->allreduce_sum(gp.d_scalar.p, 1, s);
+        HIPCHECK(hipMemcpyAsync(gp.h_scalar.p, gp.d_scalar.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        if (T->failed) return -6;
+        flag = gp.h_scalar.p[0];
+    }
+    if (flag >= 1e6) fail(ERR_DEP_TIMEOUT, "sharded solve: a multi-level launch gave up waiting for a dependency flag");
+    c.st.not_spd = flag != 0;
+    return flag != 0 ? -2 : 0;
 }
 
 // After the iterations every rank holds the states of its own subtrees and of the top fronts.  Gather: states, l_points
 // and dx masked by node ownership, summed over the ranks (x + 0 + ... + 0 is exact: every rank ends up with bit-identical
 // copies), written into the device arrays and into the caller's node objects like a resident run does.
-int shard_gather_states(april_graph_t *g, april_graph_cholesky_param_t *param) {
+static int shard_gather_states_impl(april_graph_t *g, april_graph_cholesky_param_t *param);
+int shard_gather_states(april_graph_t *g, april_graph_cholesky_param_t *param) { return guarded_rc(param, g, [&] { return shard_gather_states_impl(g, param); }); }
+static int shard_gather_states_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_shard.find(param); auto ic = g_ctx.find(param);
     if (it == g_shard.end() || ic == g_ctx.end()) return -1;
@@ -2354,7 +2572,13 @@ int shard_gather_states(april_graph_t *g, april_graph_cholesky_param_t *param) {
     return 0;
 }
 // chi^2 at the resident states: every rank sums the factors its fronts own, the transport adds the partial sums
+static double shard_chi2_impl(april_graph_t *g, april_graph_cholesky_param_t *param);
 double shard_chi2(april_graph_t *g, april_graph_cholesky_param_t *param) {
+    double out = std::nan("");
+    guarded(param, g, [&] { out = shard_chi2_impl(g, param); });
+    return out;
+}
+static double shard_chi2_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_shard.find(param); auto ic = g_ctx.find(param);
     if (it == g_shard.end() || ic == g_ctx.end()) return -1;
@@ -2465,6 +2689,7 @@ int api_set_device(int d) {
 int api_set_option(const char *name, double v) {
     load_env_options();
     std::string k(name);
+    const Options before = g_opt;
     if (k == "leaf_nodes") g_opt.leaf_nodes = (int)v;
     else if (k == "deterministic") g_opt.deterministic = (int)v;
     else if (k == "use_graph") g_opt.use_graph = (int)v;
@@ -2490,7 +2715,14 @@ int api_set_option(const char *name, double v) {
     else if (k == "left_panels") g_opt.left_panels = (int)v;
     else if (k == "batch_extend") g_opt.batch_extend = (int)v;
     else if (k == "extend_tail_fronts") g_opt.extend_tail_fronts = (int)v;
+    else if (k == "mem_cap_mb") g_opt.mem_cap_mb = (int)v;
     else return -1;
+    // host-side policies that no launch table or captured graph depends on
+    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "batch_extend",
+                                             "extend_tail_fronts", "mem_cap_mb", "medium_lds_kb" };
+    bool policy = false;
+    for (const char *q : no_replan) policy = policy || k == q;
+    if (!policy && memcmp(&before, &g_opt, sizeof(Options)) != 0) g_opt_epoch++;
     return 0;
 }
 

@@ -8,6 +8,7 @@
 // level schedule (fronts of one level are independent => one batched kernel launch).
 #include "plan.h"
 #include "solver.h"
+#include "errors.h"
 
 #include <algorithm>
 #include <cassert>
@@ -120,7 +121,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
         int par = P.f_parent[t];
         for (int64_t k = P.f_rows_ptr[t]; k < P.f_rows_ptr[t + 1]; k++) {
             int li = local_index(par, P.f_rows[k]);
-            if (li < 0) { fprintf(stderr, "aprilsam_amd: symbolic inconsistency (front %d row %d)\n", t, P.f_rows[k]); abort(); }
+            if (li < 0) fail(ERR_INTERNAL, "symbolic inconsistency (front %d row %d)", t, P.f_rows[k]);
             P.f_rel[k] = li;
         }
     }
@@ -150,7 +151,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
         int pa = P.pos[a], pb = b >= 0 ? P.pos[b] : -1;
         int t = pos_front[(pb >= 0 && pb < pa) ? pb : pa];
         int la = local_index(t, pa), lb = pb >= 0 ? local_index(t, pb) : -1;
-        if (la < 0 || (pb >= 0 && lb < 0)) { fprintf(stderr, "aprilsam_amd: factor %d not inside its front\n", f); abort(); }
+        if (la < 0 || (pb >= 0 && lb < 0)) fail(ERR_INTERNAL, "factor %d not inside its front", f);
         P.fac_front[f] = t; P.fac_la[f] = la; P.fac_lb[f] = lb;
         bd.push_back({ t, la, la, 3 * f + 0 });
         rd.push_back({ t, la, 0, 2 * f + 0 });
@@ -176,7 +177,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
         }
     };
     static_assert(sizeof(unsigned long long) == 8, "packed sort keys");
-    if ((size_t)3 * F >= (1u << 26)) { fprintf(stderr, "aprilsam_amd: too many factors for the packed sort keys\n"); abort(); }
+    if ((size_t)3 * F >= (1u << 26)) fail(ERR_UNSUPPORTED, "%d factors: this build handles up to %u (packed sort keys of the symbolic analysis)", F, (1u << 26) / 3 - 1);
     sort_dests(bd);
     sort_dests(rd);
     auto compress = [&](const std::vector<Dest> &v, std::vector<int> &front_ptr, std::vector<int> &row, std::vector<int> &col,

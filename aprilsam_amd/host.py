@@ -57,6 +57,8 @@ class SolverLib:
         for name in ("april_graph_cholesky", "april_graph_cholesky_inc"):
             getattr(d, name).argtypes = [C.POINTER(abi.Graph), C.POINTER(abi.CholeskyParam)]
             getattr(d, name).restype = None
+        d.april_graph_cholesky_inc_solver.argtypes = [C.POINTER(abi.Graph), C.POINTER(abi.CholeskyParam), _ip]
+        d.april_graph_cholesky_inc_solver.restype = None
         d.april_graph_cholesky_param_init.argtypes = [C.POINTER(abi.CholeskyParam)]
         d.april_graph_cholesky_param_destory.argtypes = [C.POINTER(abi.CholeskyParam)]
         if self.is_product:
@@ -65,6 +67,7 @@ class SolverLib:
             d.aprilsam_amd_version.restype = C.c_char_p
             d.aprilsam_amd_get_stats.argtypes = [C.POINTER(abi.CholeskyParam), C.POINTER(abi.Stats)]
             d.aprilsam_amd_set_option.argtypes = [C.c_char_p, C.c_double]
+            d.aprilsam_amd_last_error.argtypes = [C.c_char_p, C.c_int]
             d.aprilsam_amd_batch_resident.argtypes = [C.POINTER(abi.Graph), C.POINTER(abi.CholeskyParam),
                                                       C.c_int, _dp, _dp]
             for nm in ("begin", "sync", "end"):
@@ -111,6 +114,15 @@ class SolverLib:
         rc = self.dll.aprilsam_amd_set_option(name.encode(), float(value))
         if rc != 0:
             raise ValueError(f"unknown option {name}")
+
+    def last_error(self):
+        """(code, message) of the most recent failed call in this process; (0, "") when there was none"""
+        buf = C.create_string_buffer(1024)
+        code = int(self.dll.aprilsam_amd_last_error(buf, 1024))
+        return code, buf.value.decode()
+
+    def clear_error(self):
+        self.dll.aprilsam_amd_clear_error()
 
     def lattice_arrays(self, K):
         """SURVEY.md §8(d) synthetic Manhattan lattice as arrays (states, fa, fb, z, W)."""
@@ -299,6 +311,10 @@ class Graph:
 
     def cholesky_inc(self, param):
         self.lib.dll.april_graph_cholesky_inc(self.ptr, param.ptr)
+
+    def cholesky_inc_solver(self, param):
+        """april_graph_cholesky_inc_solver (aprilsam.c:578-597); neither library reads the idxs argument"""
+        self.lib.dll.april_graph_cholesky_inc_solver(self.ptr, param.ptr, None)
 
     def batch_resident(self, param, iters):
         chi2 = np.zeros(iters + 1); ms = np.zeros(iters)

@@ -217,8 +217,27 @@ typedef struct aprilsam_amd_stats {
     double ms_pack, ms_symbolic, ms_h2d, ms_device, ms_d2h, ms_unpack, ms_total;
     double ms_dev_linearize, ms_dev_factor, ms_dev_solve;   /* HIP-event timings inside ms_device */
     double chi2_before;                /* chi^2 at the linearisation point (from the linearise kernel) */
+    int    error_code;                 /* 0, or the code of the failure that ended the last call on this param (see below) */
+    int    reserved1;
 } aprilsam_amd_stats_t;
 int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_amd_stats_t *out);
+
+/* Failure path.  The reference's entry points are void and crash on bad input (assert / NULL dereference, SURVEY.md
+ * section 8(b)); this library never takes the caller's process down (one exception: no HIP device at all -- there is no CPU
+ * fallback, the first solver call aborts with a message).  A call that fails returns with the caller's node states
+ * untouched, prints one line on stderr, and leaves
+ *     -2  a pivot was not positive (stats.not_spd = 1; information matrix not positive definite)
+ *     -9  a multi-level launch gave up waiting for a dependency flag (should not happen; reported, not hung)
+ *    -10  a HIP runtime call failed                  -11  device / pinned memory exhausted (or option "mem_cap_mb")
+ *    -12  unsupported input: node type other than xyt, factor with more than two nodes, an unsplittable dense region of
+ *         more than ~6000 poses, more than 22 million factors, param->nreordering == 0 (the reference asserts)
+ *    -13  malformed graph: node index out of range, a factor connecting a node to itself, incomplete eval() result
+ *    -15  internal inconsistency of the planner
+ * in stats.error_code and in aprilsam_amd_last_error (most recent failure of the process; msg may be NULL).  The param's
+ * cached plan and factorisation are dropped: the next april_graph_cholesky starts from scratch, april_graph_cholesky_inc
+ * returns silently until then (no prior factorisation, aprilsam.c:382-383). */
+int  aprilsam_amd_last_error(char *msg, int cap);
+void aprilsam_amd_clear_error(void);
 
 /* Runtime options (also settable by env APRILSAM_AMD_<NAME>): returns 0 on success.
  *   "leaf_nodes"        nested-dissection leaf size in pose nodes (default 16)
@@ -258,7 +277,9 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *                       steps) are back-substituted column-per-lane -- one in-register chain per 64 columns; 0 = the
  *                       per-32-column-block kernel everywhere
  *   "linearize_staged_min"  graphs with at least this many factors (default 32768) write the J^T W J blocks out through
- *                       LDS with coalesced stores; smaller ones store directly (one latency chain less) */
+ *                       LDS with coalesced stores; smaller ones store directly (one latency chain less)
+ *   "mem_cap_mb"        > 0: any single device buffer above this size is refused as if the device were out of memory
+ *                       (error -11); 0 = off (default).  For testing the failure path */
 int aprilsam_amd_set_option(const char *name, double value);
 
 /* ---- device-resident benchmark/driver API: states stay in HBM between iterations -------------
