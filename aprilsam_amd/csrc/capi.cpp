@@ -88,6 +88,7 @@ long long aprilsam_amd_shard_info(const april_graph_cholesky_param_t *param, int
 int aprilsam_amd_shard_comm_unique_id(char *out128) { return asam::shard_comm_unique_id(out128); }
 int aprilsam_amd_shard_comm_init_rccl(april_graph_cholesky_param_t *param, const char *id128) { return asam::shard_comm_init_rccl(param, id128); }
 int aprilsam_amd_shard_comm_init_host(april_graph_cholesky_param_t *param, const aprilsam_amd_host_comm_t *cb) { return asam::shard_comm_init_host(param, cb); }
+int aprilsam_amd_shard_comm_info(const april_graph_cholesky_param_t *param, long long *out5, char *rccl_path, int cap) { return asam::shard_comm_info(param, out5, rccl_path, cap); }
 int aprilsam_amd_shard_iterate(april_graph_t *graph, april_graph_cholesky_param_t *param, int n) { return asam::shard_iterate(graph, param, n); }
 int aprilsam_amd_shard_gather_states(april_graph_t *graph, april_graph_cholesky_param_t *param) { return asam::shard_gather_states(graph, param); }
 double aprilsam_amd_shard_chi2(april_graph_t *graph, april_graph_cholesky_param_t *param) { return asam::shard_chi2(graph, param); }

@@ -53,6 +53,7 @@ long long shard_info(const april_graph_cholesky_param_t *param, int what, long l
 int shard_comm_unique_id(char *out128);
 int shard_comm_init_rccl(const april_graph_cholesky_param_t *param, const char *id128);
 int shard_comm_init_host(const april_graph_cholesky_param_t *param, const aprilsam_amd_host_comm_t *cb);
+int shard_comm_info(const april_graph_cholesky_param_t *param, long long *out, char *path, int cap);
 int shard_iterate(april_graph_t *g, april_graph_cholesky_param_t *param, int n);
 int shard_gather_states(april_graph_t *g, april_graph_cholesky_param_t *param);
 double shard_chi2(april_graph_t *g, april_graph_cholesky_param_t *param);

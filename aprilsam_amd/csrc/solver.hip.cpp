@@ -1752,6 +1752,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     // bookkeeping exactly as the reference: which poses solve_node visits / updates, start_over (refmodel.cpp)
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
     for (int i = 0; i < N; i++) ns[i]->UID = i;                          // aprilsam.c:474
+    const int start_over_before = c.model.start_over;
     apply_visits(c, gp, g, param, N);
     if (param->ordering) free(param->ordering);
     param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
@@ -1768,7 +1769,12 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         g_incprof.acc[0] += tp1 - t0; g_incprof.acc[1] += tp2 - tp1; g_incprof.acc[2] += tp3 - tp2; g_incprof.acc[3] += tp4 - tp3;
         g_incprof.acc[4] += tp5 - tp4; g_incprof.acc[5] += now_ms() - tp5; g_incprof.n++;
     }
-    if (!g_opt.deterministic && step_ms > param->batch_time / 3) c.model.start_over = 0x7fffffff;    // aprilsam.c:557-559
+    // aprilsam.c:557-559, the wall-clock rule: "this step took longer than a third of a batch step -> start over".  The
+    // reference sets start_over = INT_MAX BEFORE its solver call, whose walk then adds one per pose that newly crossed the
+    // relinearisation threshold (:741-747): with at least one such pose the counter wraps negative and the fall-back does
+    // NOT happen (nor any threshold fall-back until the rule fires again).  Reproduced as is: same inputs, same schedule.
+    if (!g_opt.deterministic && step_ms > param->batch_time / 3)
+        c.model.start_over = (int)(0x7fffffffu + (unsigned)(c.model.start_over - start_over_before));
     if (c.model.start_over > param->nthreshold) {                                                   // aprilsam.c:566-575
         const double b0 = now_ms();
         batch_impl(g, param);
@@ -2048,7 +2054,26 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
         // algorithmic bytes of a front: its L panel + update block written once, children's updates read once
         const double by = 8.0 * (ns * (ns + 1) / 2 + (nu + 1) * ns + (nu + 1) * (nu + 2) / 2);
         if (small) { flops[K_FRONT_SMALL] += fl; bytes[K_FRONT_SMALL] += by; }
-        else { flops[K_SYRK_BIG] += fl; bytes[K_SYRK_BIG] += by; bytes[K_ASSEMBLE_BIG] += by; }      // (assembly: the front written once, children's updates read once)
+        else {
+            // multi-workgroup path.  k_syrk_big gets exactly what its launches are asked for: per outer block of OBP panels the
+            // K = block-width update of the lower trapezoid to the right of the block, 2 K flops per element (the kernel also
+            // multiplies the upper halves of its diagonal tiles: executed, not algorithmic, not counted); with right-looking
+            // panels (left_panels = 0) also the narrow updates inside the block.  The panel kernel (k_diagpanel_ll) gets the
+            // rest of the front's sum c_j^2: diagonal blocks, row solves, the left-looking K <= 96 products.
+            const double Rv = R - 2;
+            double fsy = 0;
+            auto trapezoid = [&](double c_lo, double c_hi) { const double n = c_hi - c_lo; return n <= 0 ? 0.0 : n * Rv - (c_lo + c_hi - 1) * n / 2; };   // elements (i >= j) of columns [c_lo, c_hi), rows < Rv
+            const int steps = ((int)ns + NB - 1) / NB;
+            for (int o = 0; o * OBP < steps; o++) {
+                const double k_lo = (double)o * OBP * NB, k_hi = std::min<double>(ns, (double)(o + 1) * OBP * NB);
+                fsy += 2.0 * (k_hi - k_lo) * trapezoid(k_hi, C);
+                if (!(g_opt.left_panels && g_opt.fused_panel))
+                    for (double k1 = k_lo + NB; k1 < k_hi; k1 += NB) fsy += 2.0 * NB * trapezoid(k1, k_hi);
+            }
+            fsy = std::min(fsy, fl);
+            flops[K_SYRK_BIG] += fsy; flops[K_PANEL_BIG] += fl - fsy;
+            bytes[K_SYRK_BIG] += by; bytes[K_ASSEMBLE_BIG] += by;      // (assembly: the front written once, children's updates read once)
+        }
         bytes[K_BACKSOLVE] += 8.0 * (ns * (ns + 1) / 2 + nu * ns) + 16.0 * (ns + nu);
         flops[K_BACKSOLVE] += 2.0 * (ns * (ns + 1) / 2 + nu * ns);
     }
@@ -2185,6 +2210,8 @@ struct RcclApi {
     decltype(&ncclBroadcast) Broadcast = nullptr; decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr; decltype(&ncclCommUserRank) CommUserRank = nullptr; decltype(&ncclGetVersion) GetVersion = nullptr;
+    std::string path;
     bool load() {
         if (h) return true;
         // the RCCL that belongs to the HIP runtime THIS library runs on: same directory as the libamdhip64 we are linked to.
@@ -2194,11 +2221,12 @@ struct RcclApi {
         Dl_info di;
         if (dladdr((const void *)&hipStreamSynchronize, &di) && di.dli_fname) { dir = di.dli_fname; const size_t k = dir.rfind('/'); dir = k == std::string::npos ? "" : dir.substr(0, k + 1); }
         const std::string cand[] = { dir + "librccl.so.1", dir + "librccl.so", "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so" };
-        for (const std::string &nm : cand) { if (nm.empty()) continue; h = dlopen(nm.c_str(), RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        for (const std::string &nm : cand) { if (nm.empty()) continue; h = dlopen(nm.c_str(), RTLD_NOW | RTLD_LOCAL); if (h) { path = nm; break; } }
         if (!h) return false;
 #define RCCL_SYM(x) x = (decltype(x))dlsym(h, "nccl" #x); if (!x) return false
         RCCL_SYM(GetUniqueId); RCCL_SYM(CommInitRank); RCCL_SYM(CommDestroy); RCCL_SYM(Send); RCCL_SYM(Recv); RCCL_SYM(Broadcast);
         RCCL_SYM(AllReduce); RCCL_SYM(GroupStart); RCCL_SYM(GroupEnd); RCCL_SYM(GetErrorString);
+        RCCL_SYM(CommCount); RCCL_SYM(CommUserRank); RCCL_SYM(GetVersion);
 #undef RCCL_SYM
         return true;
     }
@@ -2433,6 +2461,25 @@ static int shard_comm_init_rccl_impl(const april_graph_cholesky_param_t *param, 
     const ncclResult_t r = g_rccl.CommInitRank(&T->comm, S.world, id, S.rank);
     if (r != ncclSuccess) { fprintf(stderr, "aprilsam_amd: ncclCommInitRank failed: %s\n", g_rccl.GetErrorString(r)); return -6; }
     S.tr = std::move(T);
+    return 0;
+}
+// what the attached transport is, as the communication library itself reports it: out = {kind (0 none, 1 RCCL, 2 host
+// callbacks), ncclCommCount, ncclCommUserRank, ncclGetVersion code, HIP device}; path (may be null) receives the librccl
+// file the symbols came from
+int shard_comm_info(const april_graph_cholesky_param_t *param, long long *out, char *path, int cap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_shard.find(param);
+    if (it == g_shard.end()) return -1;
+    ShardState &S = *it->second;
+    out[0] = 0; out[1] = S.world; out[2] = S.rank; out[3] = 0; out[4] = g_device;
+    if (path && cap > 0) path[0] = 0;
+    if (!S.tr) return 0;
+    if (auto *R = dynamic_cast<RcclTransport *>(S.tr.get())) {
+        int cnt = -1, ur = -1, ver = 0;
+        (void)g_rccl.CommCount(R->comm, &cnt); (void)g_rccl.CommUserRank(R->comm, &ur); (void)g_rccl.GetVersion(&ver);
+        out[0] = 1; out[1] = cnt; out[2] = ur; out[3] = ver;
+        if (path && cap > 0) { strncpy(path, g_rccl.path.c_str(), (size_t)cap - 1); path[cap - 1] = 0; }
+    } else out[0] = 2;
     return 0;
 }
 int shard_comm_init_host(const april_graph_cholesky_param_t *param, const aprilsam_amd_host_comm_t *cb) {

@@ -123,6 +123,17 @@ class ShardedSolver:
             raise RuntimeError(f"shard_gather_states rc={rc}")
         return self.g.states()
 
+    def comm_info(self):
+        """what the attached transport is, as RCCL itself reports it (aprilsam_amd_shard_comm_info)"""
+        out = (C.c_longlong * 5)(); path = C.create_string_buffer(512)
+        self.lib.dll.aprilsam_amd_shard_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_char_p, C.c_int]
+        self.lib.dll.aprilsam_amd_shard_comm_info(self._p, out, path, 512)
+        kind = {0: "none (single rank)", 1: "RCCL point-to-point on the solver stream", 2: "host callbacks over " + self.backend}[int(out[0])]
+        v = int(out[3])
+        return {"transport": kind, "ncclCommCount": int(out[1]), "ncclCommUserRank": int(out[2]),
+                "rccl_version": f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v else None, "librccl": path.value.decode() or None,
+                "hip_device": int(out[4])}
+
     def comm_bytes_per_iteration(self):
         return int(8 * (self.xfer[:, 5].sum() + 3 * self.bcast[:, 4].sum() * (self.world - 1)))
 

@@ -348,6 +348,9 @@ long long aprilsam_amd_shard_info(const april_graph_cholesky_param_t *param, int
 int       aprilsam_amd_shard_comm_unique_id(char *out128);
 int       aprilsam_amd_shard_comm_init_rccl(april_graph_cholesky_param_t *param, const char *id128);
 int       aprilsam_amd_shard_comm_init_host(april_graph_cholesky_param_t *param, const aprilsam_amd_host_comm_t *callbacks);
+/* the attached transport as the communication library reports it: out5 = {kind (0 none, 1 RCCL, 2 host callbacks),
+ * ncclCommCount, ncclCommUserRank, ncclGetVersion code, HIP device}; rccl_path (may be NULL): the librccl file in use */
+int       aprilsam_amd_shard_comm_info(const april_graph_cholesky_param_t *param, long long *out5, char *rccl_path, int cap);
 int       aprilsam_amd_shard_iterate(april_graph_t *graph, april_graph_cholesky_param_t *param, int n);
 int       aprilsam_amd_shard_gather_states(april_graph_t *graph, april_graph_cholesky_param_t *param);
 double    aprilsam_amd_shard_chi2(april_graph_t *graph, april_graph_cholesky_param_t *param);
