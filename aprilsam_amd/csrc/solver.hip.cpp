@@ -81,6 +81,7 @@ static void load_env_options() {
         v = g_opt.linearize_staged_min; envd("APRILSAM_AMD_LINEARIZE_STAGED_MIN", &v); g_opt.linearize_staged_min = (int)v;
         v = g_opt.wave_backsolve; envd("APRILSAM_AMD_WAVE_BACKSOLVE", &v); g_opt.wave_backsolve = (int)v;
         v = g_opt.left_panels; envd("APRILSAM_AMD_LEFT_PANELS", &v); g_opt.left_panels = (int)v;
+        v = g_opt.block_panels; envd("APRILSAM_AMD_BLOCK_PANELS", &v); g_opt.block_panels = (int)v;
         v = g_opt.batch_extend; envd("APRILSAM_AMD_BATCH_EXTEND", &v); g_opt.batch_extend = (int)v;
         v = g_opt.extend_tail_fronts; envd("APRILSAM_AMD_EXTEND_TAIL_FRONTS", &v); g_opt.extend_tail_fronts = (int)v;
         v = g_opt.mem_cap_mb; envd("APRILSAM_AMD_MEM_CAP_MB", &v); g_opt.mem_cap_mb = (int)v;
@@ -401,6 +402,7 @@ struct LevelPlan {
     Launch asm_big{};                                          // k_assemble_big
     std::vector<Launch> syrka, syrkb;                          // look-ahead split of the wide update (modes 2, 3), same indexing as syrkw
     std::vector<Launch> panel, syrk, syrkw;                    // per panel step: diag+panel, narrow update, wide update (grid 0 unless the step closes an outer block)
+    std::vector<Launch> bchain, btile;                         // per outer block (option block_panels): diagonal-block workgroups, row tiles (Launch::tile = rows per wave / 16)
     std::vector<int> diag_slot0;                               // per panel step: first slot of its factored diagonal blocks in d_diag (multi-tile steps)
     int wb_off = 0, n_wb = 0, n_diag_slots = 0;                // k_diag_writeback entries (3 ints each) of the level, slots used
     int all_off = 0, n_all = 0; size_t solve_lds = 0;          // every front (k_backsolve)
@@ -601,6 +603,11 @@ static int waves_of(int nt) { return nt >= 1024 ? 16 : (nt >= 512 ? 8 : 4); }
 // front's critical path), throughput levels the smaller one (more workgroups per CU)
 static int small_threads_for(size_t n_fronts) { return (int)n_fronts >= g_opt.tp_fronts ? std::min(g_opt.small_threads, g_opt.tp_threads) : g_opt.small_threads; }
 
+// doubles of d_diag a level needs: one (NB x NB+1) slot per parked diagonal block (per-panel forms) or four NB x NB inverse
+// blocks per active front (outer-block panels)
+static size_t diag_doubles(int n_big, int n_diag_slots) {
+    return std::max((size_t)(std::max(n_big, n_diag_slots) + 64) * NB * (NB + 1), (size_t)std::max(n_big, 1) * OBP * NB * NB);
+}
 // classify the fronts of one level (small / big) and append their launch tables to `tab`
 template <class Dims>
 static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int> &tab, Dims dims) {
@@ -688,6 +695,18 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     }
     L.wb_off = (int)tab.size(); L.n_wb = (int)wb.size() / 3;
     tab.insert(tab.end(), wb.begin(), wb.end());
+    // outer-block panels (kernels.hip.h: k_block_chain / k_block_solve): per 128-column outer block the active fronts (a
+    // prefix of `big`, sorted by own columns) and their row tiles below the diagonal block
+    for (int o = 0; o * OBP < steps; o++) {
+        const int nact = active(o * OBP);
+        Launch bc{ list_off, 0, nact, nact, true };
+        L.bchain.push_back(bc);
+        long long tiles1 = 0;
+        for (int i = 0; i < nact; i++) tiles1 += block_tiles(rows(big[i]), 3 * nsb_of(big[i]), o, 1);
+        const int rb = tiles1 > 1024 ? 2 : 1;          // many tiles: 32 rows per wave (half the workgroups, each staging the same L11 once)
+        L.btile.push_back(make(nact, [&](int t) { return block_tiles(rows(t), 3 * nsb_of(t), o, rb); }));
+        L.btile.back().tile = rb;
+    }
 }
 
 // Per-rank layout of the front pool in a sharded run: a rank keeps the frontal arrays of the fronts it OWNS and, for
@@ -811,7 +830,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.inc.slots_used = P.n_slots;
     c.inc.ready = false; c.inc.t_first.clear(); c.same_topo_batches = 0;
     c.d_bad.need(4); c.h_bad.need(4);
-    { int mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max({ mx, c.levels[l].n_big, c.levels[l].n_diag_slots }); c.d_diag.need((size_t)(mx + 64) * NB * (NB + 1)); }
+    { size_t mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, diag_doubles(c.levels[l].n_big, c.levels[l].n_diag_slots)); c.d_diag.need(mx); }
     c.st.n_fronts = P.nF; c.st.n_levels = P.nLevels; c.st.max_front_rows = P.max_rows;
     c.st.nnz_L = P.nnzL; c.st.flops_factor = P.flops; c.st.bytes_fronts = 8.0 * (double)pool_doubles;
 }
@@ -826,6 +845,9 @@ static void set_small_attr() {
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_w, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_block_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_block_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_block_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
 }
 
@@ -877,6 +899,24 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
         else
             hipLaunchKernelGGL(k_syrk_big, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
     };
+    if (g_opt.block_panels && !la) {
+        // outer-block panels: per 128-column outer block {diagonal block in LDS, row solves on the matrix cores, wide update}
+        const int steps = (int)L.panel.size();
+        for (size_t o = 0; o < L.bchain.size(); o++) {
+            const Launch &bc = L.bchain[o], &bt = L.btile[o];
+            tic(K_PANEL_BIG);
+            hipLaunchKernelGGL(k_block_chain, dim3(bc.n), dim3(1024), block_chain_lds(), s, c.dp, tab + bc.list_off, (int)o, c.d_pool.p, c.d_diag.p, c.d_bad.p);
+            if (bt.grid > 0) {
+                if (bt.tile == 2) hipLaunchKernelGGL(k_block_solve<2>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p);
+                else hipLaunchKernelGGL(k_block_solve<1>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p);
+            }
+            toc();
+            const int k = std::min((int)(o + 1) * OBP, steps) - 1;      // the panel step that closes the outer block carries its wide update
+            const Launch &sw = L.syrkw[k];
+            if (sw.grid > 0) { tic(K_SYRK_BIG); wide(sw, k, 1, s); toc(); }
+        }
+        return;
+    }
     if (la && !c.s2) {        // lowest priority: its big kernels must not delay the one-workgroup kernels of the chain
         int lo = 0, hi = 0;
         HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -1378,10 +1418,12 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrka) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrkb) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.bchain) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.btile) { x.list_off += sh; x.pre_off += sh; }
         L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh; L.wb_off += sh;
         if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
     }
-    for (int l = 0; l < nLev; l++) if ((size_t)(std::max(dl[l].n_big, dl[l].n_diag_slots) + 64) * NB * (NB + 1) > c.d_diag.cap) return false;
+    for (int l = 0; l < nLev; l++) if (diag_doubles(dl[l].n_big, dl[l].n_diag_slots) > c.d_diag.cap) return false;
     // batch on the extended plan: levels >= 1 as ONE multi-level launch per sweep (see enqueue_numeric), when they hold small
     // fronts only
     int mp_up_off = 0, mp_dn_off = 0, mp_n = 0, mp_nt = 0; size_t mp_up_lds = 0, mp_dn_lds = 0; long long mp_full = 0; int mp_dn_maxns = 0;
@@ -1647,6 +1689,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         printf("aprilsam_amd batch: N=%d F=%d fronts=%d levels=%d | pack %.3f symbolic %.3f%s upload %.3f device %.3f unpack %.3f | total %.3f ms\n",
                N, F, c.st.n_fronts, c.st.n_levels, c.st.ms_pack, c.st.ms_symbolic, reused ? " (cached)" : "", c.st.ms_h2d, c.st.ms_device,
                c.st.ms_unpack, c.st.ms_total);
+        fflush(stdout);
     }
 }
 
@@ -1764,7 +1807,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (param->show_timing)
         printf("aprilsam_amd inc: N=%d F=%d fronts=%d (%d regenerated) marked=%d visited=%zu%s | pack %.3f model %.3f plan+enqueue %.3f device %.3f | total %.3f ms\n",
                N, F, c.st.n_fronts, reused ? c.st.reserved0 : c.st.n_fronts, c.model.naffected, c.visits.size(), reused ? "" : " (re-planned)",
-               tp1 - t0, tp2 - tp1, tp4 - tp3, tp5 - tp4, step_ms);
+               tp1 - t0, tp2 - tp1, tp4 - tp3, tp5 - tp4, step_ms), fflush(stdout);
     if (g_incprof.on) {
         g_incprof.acc[0] += tp1 - t0; g_incprof.acc[1] += tp2 - tp1; g_incprof.acc[2] += tp3 - tp2; g_incprof.acc[3] += tp4 - tp3;
         g_incprof.acc[4] += tp5 - tp4; g_incprof.acc[5] += now_ms() - tp5; g_incprof.n++;
@@ -1882,7 +1925,7 @@ void inc_solve_only(april_graph_t *g, april_graph_cholesky_param_t *param) {
         HIPCHECK(hipStreamSynchronize(s));
         apply_visits(c, gp, g, param, N);
         c.st.error_code = 0; c.st.ms_total = now_ms() - t0;
-        if (param->show_timing) printf("aprilsam_amd solve: N=%d visited %zu poses%s | total %.3f ms\n", N, c.visits.size(), partial ? " (marked root paths only)" : "", c.st.ms_total);
+        if (param->show_timing) { printf("aprilsam_amd solve: N=%d visited %zu poses%s | total %.3f ms\n", N, c.visits.size(), partial ? " (marked root paths only)" : "", c.st.ms_total); fflush(stdout); }
     });
 }
 
@@ -2067,7 +2110,7 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
             for (int o = 0; o * OBP < steps; o++) {
                 const double k_lo = (double)o * OBP * NB, k_hi = std::min<double>(ns, (double)(o + 1) * OBP * NB);
                 fsy += 2.0 * (k_hi - k_lo) * trapezoid(k_hi, C);
-                if (!(g_opt.left_panels && g_opt.fused_panel))
+                if (!g_opt.block_panels && !(g_opt.left_panels && g_opt.fused_panel))
                     for (double k1 = k_lo + NB; k1 < k_hi; k1 += NB) fsy += 2.0 * NB * trapezoid(k1, k_hi);
             }
             fsy = std::min(fsy, fl);
@@ -2386,7 +2429,7 @@ static int shard_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *para
     if (tab.empty()) tab.push_back(0);
     S.d_tab.need(tab.size());
     HIPCHECK(hipMemcpyAsync(S.d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, gp.stream));
-    { int mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max({ mx, S.levels[l].n_big, S.levels[l].n_diag_slots }); c.d_diag.need((size_t)(mx + 64) * NB * (NB + 1)); }
+    { size_t mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, diag_doubles(S.levels[l].n_big, S.levels[l].n_diag_slots)); c.d_diag.need(mx); }
     // ---- factors owned by this rank's fronts, node ownership ----------------------------------------------------
     std::vector<int> fl;
     for (int f = 0; f < P.F; f++) if (P.fac_front[f] >= 0 && S.owner[P.fac_front[f]] == rank) fl.push_back(f);
@@ -2760,6 +2803,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "linearize_staged_min") g_opt.linearize_staged_min = (int)v;
     else if (k == "wave_backsolve") g_opt.wave_backsolve = (int)v;
     else if (k == "left_panels") g_opt.left_panels = (int)v;
+    else if (k == "block_panels") g_opt.block_panels = (int)v;
     else if (k == "batch_extend") g_opt.batch_extend = (int)v;
     else if (k == "extend_tail_fronts") g_opt.extend_tail_fronts = (int)v;
     else if (k == "mem_cap_mb") g_opt.mem_cap_mb = (int)v;

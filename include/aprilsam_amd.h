@@ -270,7 +270,10 @@ void aprilsam_amd_clear_error(void);
  *                       per-front dependency flags; 0 = one launch per level
  *   "fused_panel"       0 = diagonal block and row solves of a multi-tile panel step as two kernels (default 1: one)
  *   "lookahead"         1 = wide trailing updates split, the far part on a side stream (default 0: measured no gain)
- *   "left_panels"       1 (default): inside a 128-column outer block of a multi-workgroup front every panel step applies the
+ *   "block_panels"      1 (default): multi-workgroup fronts run the four panel steps of a 128-column outer block as two launches --
+ *                       the 128 x 128 diagonal block factored in LDS by one workgroup, the rows below solved against it on the
+ *                       matrix cores (explicit inverses of its 32 x 32 diagonal blocks); 0 = one launch per 32-column panel
+ *   "left_panels"       (block_panels = 0) 1 (default): inside a 128-column outer block of a multi-workgroup front every panel step applies the
  *                       earlier panels' updates to its own 32 columns itself (MFMA, overlapped with the pivot chain) instead
  *                       of a "narrow" update launch after every panel; 0 = right-looking narrow updates
  *   "wave_backsolve"    1 (default): fronts whose L panel fits LDS (multi-level launch, latency-bound levels, incremental

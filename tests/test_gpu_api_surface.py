@@ -104,27 +104,38 @@ def test_inc_solver_called_directly_matches_the_live_reference(lib, reflib):
 
 
 def test_wall_clock_rule_follows_the_reference_when_batch_time_is_injected(lib, reflib):
-    """aprilsam.c:557-559: `if (step_ms > batch_time / 3) start_over = INT_MAX` -> batch fall-back.  The rule is ON by default
-    (option deterministic = 0), as in the reference.  batch_time = -1 before a call makes it fire whatever the clock says,
-    1e300 keeps it quiet: the same schedule on both libraries gives the same states; the fall-back shows as a rewritten
-    batch_time (:569-572).  With deterministic = 1 this library ignores the rule."""
+    """aprilsam.c:557-559: `if (step_ms > batch_time / 3) start_over = INT_MAX` -> batch fall-back (:566-575).  The rule is ON by
+    default (option deterministic = 0), as in the reference.  batch_time = -1 before a call makes it fire whatever the clock
+    says, 1e300 keeps it quiet; a fall-back shows as a rewritten batch_time (:569-572).
+      * relinearisation thresholds out of reach: the rule alone decides -> a fall-back exactly at the injected steps;
+      * realistic thresholds: the reference sets INT_MAX BEFORE its solver call, whose walk adds one per pose that newly
+        crossed the threshold (:741-747) -- the counter wraps negative and the fall-back does NOT happen.  Reproduced as is:
+        the same schedule on both libraries gives the same fall-backs and the same states.
+    With deterministic = 1 this library ignores the rule."""
     sched = [(-1.0 if k % 5 == 2 else 1e300) for k in range(45)]
-    runs, fell = [], []
-    for L in (lib, reflib):
-        w = Walk(L, 23)
-        tr, fb = [], []
-        for bt in sched:
-            w.grow(); w.inc(bt)
-            fb.append(w.p.c.batch_time != bt)
-            tr.append(w.snap())
-        runs.append(tr); fell.append(fb)
-        w.close()
-    assert fell[0] == fell[1] == [bt < 0 for bt in sched]
-    for k, (a, b) in enumerate(zip(*runs)):
-        _same(a, b, what=f"step {k}")
+    for delta, expect_all in ((50.0, True), (0.05, False)):
+        runs, fell = [], []
+        for L in (lib, reflib):
+            w = Walk(L, 23, delta=delta)
+            tr, fb = [], []
+            for bt in sched:
+                w.grow(); w.inc(bt)
+                fb.append(w.p.c.batch_time != bt)
+                tr.append(w.snap())
+            runs.append(tr); fell.append(fb)
+            w.close()
+        assert fell[0] == fell[1], (delta, fell)
+        fired = [bt < 0 for bt in sched]
+        if expect_all:
+            assert fell[1] == fired
+        else:
+            assert not any(f and not r for f, r in zip(fell[1], fired))           # never without the rule (nthreshold is out of reach)
+            assert sum(fell[1]) < sum(fired)                                     # the wrap swallowed some of them
+        for k, (a, b) in enumerate(zip(*runs)):
+            _same(a, b, what=f"delta {delta} step {k}")
     lib.set_option("deterministic", 1)
     try:
-        w = Walk(lib, 23)
+        w = Walk(lib, 23, delta=50.0)
         for bt in sched[:12]:
             w.grow(); w.inc(bt)
             assert w.p.c.batch_time == bt                # no fall-back, nothing rewrote it
@@ -312,14 +323,14 @@ def test_malformed_and_unsupported_graphs_are_refused_without_abort(lib):
 # ---- plan cache vs options / edits ----------------------------------------------------------------------------------------
 def test_options_changed_on_a_param_with_a_cached_plan_force_a_replan(lib, oracle):
     """launch tables are built for the options in force at plan time and read again at enqueue time: toggling
-    left_panels / fused_panel / small_lds_kb on a warm param (no graph replay, so the live enqueue code runs) must re-plan"""
+    block_panels / left_panels / fused_panel / small_lds_kb on a warm param (no graph replay, so the live enqueue code runs) must re-plan"""
     arr = lib.lattice_arrays(40)
     oc, ost = oracle.iterate(arr, 1)
     lib.set_option("use_graph", 0); lib.set_option("small_lds_kb", 0)
     try:
         g = lib.new_graph(); g.build_from_arrays(*arr); p = lib.new_param()
         st0 = g.states().copy()
-        for name, val in (("left_panels", 0), ("fused_panel", 0), ("left_panels", 1), ("small_lds_kb", 64), ("fused_panel", 1)):
+        for name, val in (("block_panels", 0), ("left_panels", 0), ("fused_panel", 0), ("left_panels", 1), ("small_lds_kb", 64), ("fused_panel", 1), ("block_panels", 1)):
             g.cholesky(p)
             assert p.stats()["not_spd"] == 0 and np.max(np.abs(g.states() - ost)) < 1e-6, name
             for i in range(g.n_nodes):
@@ -332,7 +343,7 @@ def test_options_changed_on_a_param_with_a_cached_plan_force_a_replan(lib, oracl
                 g.set_state(i, st0[i])
         p.destroy(); g.destroy()
     finally:
-        for name, val in (("use_graph", 1), ("small_lds_kb", 156), ("left_panels", 1), ("fused_panel", 1)):
+        for name, val in (("use_graph", 1), ("small_lds_kb", 156), ("left_panels", 1), ("fused_panel", 1), ("block_panels", 1)):
             lib.set_option(name, val)
 
 
