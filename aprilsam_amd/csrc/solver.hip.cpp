@@ -905,7 +905,7 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
         for (size_t o = 0; o < L.bchain.size(); o++) {
             const Launch &bc = L.bchain[o], &bt = L.btile[o];
             tic(K_PANEL_BIG);
-            hipLaunchKernelGGL(k_block_chain, dim3(bc.n), dim3(1024), block_chain_lds(), s, c.dp, tab + bc.list_off, (int)o, c.d_pool.p, c.d_diag.p, c.d_bad.p);
+            hipLaunchKernelGGL(k_block_chain, dim3(bc.n), dim3(BCH_THREADS), block_chain_lds(), s, c.dp, tab + bc.list_off, (int)o, c.d_pool.p, c.d_diag.p, c.d_bad.p);
             if (bt.grid > 0) {
                 if (bt.tile == 2) hipLaunchKernelGGL(k_block_solve<2>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p);
                 else hipLaunchKernelGGL(k_block_solve<1>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p);
