@@ -771,7 +771,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.inc.o_rows = (long long)o_rows; c.inc.o_rel = (long long)o_rel;
     d.lambda = c.d_lambda.p;
     d.prof = nullptr; d.prof_mode = 0;
-    if (getenv("APRILSAM_AMD_KPROF")) { c.d_prof.need((size_t)PROF_SLOTS * P.nF); HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)8 * PROF_SLOTS * P.nF, s)); d.prof = c.d_prof.p; d.prof_mode = atoi(getenv("APRILSAM_AMD_KPROF")) == 2 ? 2 : 1; }
+    if (getenv("APRILSAM_AMD_KPROF")) { c.d_prof.need((size_t)PROF_SLOTS * P.nF); HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)8 * PROF_SLOTS * P.nF, s)); d.prof = c.d_prof.p; d.prof_mode = atoi(getenv("APRILSAM_AMD_KPROF")) >= 2 ? atoi(getenv("APRILSAM_AMD_KPROF")) : 1; }
     c.d_swap.need((size_t)P.F + INC_FACT_); c.d_pos.need((size_t)P.N + INC_NODES_);
     HIPCHECK(hipMemcpyAsync(c.d_swap.p, P.fac_swap.data(), P.F, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_pos.p, P.pos.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
@@ -899,9 +899,18 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
         else
             hipLaunchKernelGGL(k_syrk_big, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
     };
-    if (g_opt.block_panels && !la) {
-        // outer-block panels: per 128-column outer block {diagonal block in LDS, row solves on the matrix cores, wide update}
+    if (la && !c.s2) {        // lowest priority: its big kernels must not delay the one-workgroup kernels of the chain
+        int lo = 0, hi = 0;
+        HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHECK(hipStreamCreateWithPriority(&c.s2, hipStreamNonBlocking, lo));
+    }
+    if (g_opt.block_panels) {
+        // outer-block panels: per 128-column outer block {diagonal block in LDS, row solves on the matrix cores, wide update}.
+        // Look-ahead (la): the wide update is split -- "ahead" = the next outer block's columns, on this stream, all the next
+        // diagonal block and row solves need; "rest" = everything right of them, on the side stream beside that chain.  Both
+        // write disjoint columns; the next "ahead" and "rest" touch columns the previous "rest" wrote, so they wait for it.
         const int steps = (int)L.panel.size();
+        hipEvent_t rest_done = nullptr;
         for (size_t o = 0; o < L.bchain.size(); o++) {
             const Launch &bc = L.bchain[o], &bt = L.btile[o];
             tic(K_PANEL_BIG);
@@ -912,15 +921,26 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
             }
             toc();
             const int k = std::min((int)(o + 1) * OBP, steps) - 1;      // the panel step that closes the outer block carries its wide update
-            const Launch &sw = L.syrkw[k];
-            if (sw.grid > 0) { tic(K_SYRK_BIG); wide(sw, k, 1, s); toc(); }
+            if (!la) {
+                const Launch &sw = L.syrkw[k];
+                if (sw.grid > 0) { tic(K_SYRK_BIG); wide(sw, k, 1, s); toc(); }
+                continue;
+            }
+            const Launch &sa = L.syrka[k], &sb = L.syrkb[k];
+            if (sb.grid > 0) {
+                hipEvent_t solved = c.la_event();
+                HIPCHECK(hipEventRecord(solved, s));
+                HIPCHECK(hipStreamWaitEvent(c.s2, solved, 0));
+                wide(sb, k, 3, c.s2);                       // (same stream as the previous "rest": in order behind it)
+            }
+            if (sa.grid > 0) {
+                if (rest_done) HIPCHECK(hipStreamWaitEvent(s, rest_done, 0));
+                wide(sa, k, 2, s);
+            }
+            if (sb.grid > 0) { rest_done = c.la_event(); HIPCHECK(hipEventRecord(rest_done, c.s2)); }
         }
+        if (rest_done) HIPCHECK(hipStreamWaitEvent(s, rest_done, 0));      // join: the next level reads the update blocks
         return;
-    }
-    if (la && !c.s2) {        // lowest priority: its big kernels must not delay the one-workgroup kernels of the chain
-        int lo = 0, hi = 0;
-        HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHECK(hipStreamCreateWithPriority(&c.s2, hipStreamNonBlocking, lo));
     }
     hipEvent_t rest_done = nullptr;          // completion of the latest "rest" update on the side stream
     for (size_t k = 0; k < L.panel.size(); k++) {
