@@ -114,6 +114,7 @@ void aprilsam_amd_refmodel_get(void *m, int *parent, int *changed, int *relin) {
     asam::RefModel *M = (asam::RefModel *)m;
     for (int i = 0; i < M->N; i++) { if (parent) parent[i] = M->parent[i]; if (changed) changed[i] = M->changed[i]; if (relin) relin[i] = M->relin[i]; }
 }
+int aprilsam_amd_refmodel_check(void *m) { return ((asam::RefModel *)m)->check_tree(); }
 int aprilsam_amd_last_error(char *msg, int cap) { return asam::get_last_error(msg, cap); }
 void aprilsam_amd_clear_error(void) { asam::clear_last_error(); }
 int aprilsam_amd_selftest(void) { return asam::selftest(); }

@@ -159,6 +159,31 @@ void RefModel::add_factor_edges(int a, int b) {
     ins(a, b); ins(b, a);
 }
 
+void RefModel::set_parent(int v, int p) {
+    const int old = parent[v];
+    if (old == p) return;
+    if (old >= 0) { auto &k = kids[old]; k.erase(std::find(k.begin(), k.end(), v)); }
+    parent[v] = p;
+    if (p >= 0) kids[p].push_back(v);
+}
+
+// The elimination tree after one more edge (u, v), without recomputing it: the root paths of the two poses merge into one
+// chain, in elimination order, up to their first common ancestor (Liu's path merging).  a is the earlier pose, b must
+// become its ancestor: climb from a while the ancestors still precede b, splice b in where they stop, then go on with b and
+// the displaced ancestor.  Every step moves up a root path, so an insertion costs the length of the two paths -- the full
+// recomputation it replaces (block_etree, all N poses) was a third of an incremental step's host time on M3500.
+void RefModel::insert_edge(int u, int v) {
+    if (v < 0 || u == v) return;
+    int a = pos[u] < pos[v] ? u : v, b = pos[u] < pos[v] ? v : u;
+    for (;;) {
+        const int p = parent[a];
+        if (p == b) break;
+        if (p == -1) { set_parent(a, b); break; }
+        if (pos[p] < pos[b]) a = p;
+        else { set_parent(a, b); a = b; b = p; }
+    }
+}
+
 // after a batch step on the first n_nodes nodes / n_factors factors (aprilsam.c:121,269)
 void RefModel::batch(int n_nodes, int n_factors, const int *fa, const int *fb) {
     N = n_nodes; F = n_factors;
@@ -168,6 +193,8 @@ void RefModel::batch(int n_nodes, int n_factors, const int *fa, const int *fb) {
     pos.assign(N, -1);
     for (int p = 0; p < N; p++) pos[ord[p]] = p;
     block_etree(N, adj, ord, pos, parent);
+    kids.assign(N, {});
+    for (int i = 0; i < N; i++) if (parent[i] >= 0) kids[parent[i]].push_back(i);
     changed.assign(N, 0); relin.assign(N, 0);
     start_over = 0; naffected = 0;
     root = N > 0 ? ord[N - 1] : -1;
@@ -178,7 +205,7 @@ void RefModel::batch(int n_nodes, int n_factors, const int *fa, const int *fb) {
 // the OLD tree, then re-parent (the structure of U after the partial re-factorisation)
 void RefModel::inc_begin(int n_nodes, int n_factors, const int *fa, const int *fb) {
     const int oldN = N;
-    adj.resize(n_nodes); parent.resize(n_nodes, -1); changed.resize(n_nodes, 0); relin.resize(n_nodes, 0);
+    adj.resize(n_nodes); parent.resize(n_nodes, -1); changed.resize(n_nodes, 0); relin.resize(n_nodes, 0); kids.resize(n_nodes);
     for (int i = oldN; i < n_nodes; i++) { ord.push_back(i); pos.push_back(i); }
     naffected = 0;
     for (int f = F; f < n_factors; f++) {
@@ -191,10 +218,20 @@ void RefModel::inc_begin(int n_nodes, int n_factors, const int *fa, const int *f
             }
         }
     }
-    for (int f = F; f < n_factors; f++) add_factor_edges(fa[f], fb[f]);
+    for (int f = F; f < n_factors; f++) { add_factor_edges(fa[f], fb[f]); insert_edge(fa[f], fb[f]); }
     N = n_nodes; F = n_factors;
-    block_etree(N, adj, ord, pos, parent);
     root = ord[N - 1];
+}
+
+// the incrementally maintained tree against a full recomputation (tests): 0 = identical
+int RefModel::check_tree() const {
+    std::vector<int> full;
+    block_etree(N, adj, ord, pos, full);
+    for (int i = 0; i < N; i++) if (full[i] != parent[i]) return i + 1;
+    std::vector<int> cnt(N, 0);
+    for (int i = 0; i < N; i++) { for (int k : kids[i]) { if (parent[k] != i) return -(i + 1); cnt[k]++; } }
+    for (int i = 0; i < N; i++) if (cnt[i] != (parent[i] >= 0 ? 1 : 0)) return -(N + i + 1);
+    return 0;
 }
 
 // aprilsam.c:721-779, split in two: the traversal is purely structural (labels + tree), so it can be planned
@@ -203,11 +240,7 @@ void RefModel::inc_begin(int n_nodes, int n_factors, const int *fa, const int *f
 // false -> only delta_X = x (an unmarked child reached when naffected <= 5; the walk stops there).
 void RefModel::plan_visit(std::vector<Visit> &out) {
     out.clear();
-    std::vector<int> cptr(N + 1, 0), cidx(N);
-    for (int i = 0; i < N; i++) if (parent[i] >= 0) cptr[parent[i] + 1]++;
-    for (int i = 0; i < N; i++) cptr[i + 1] += cptr[i];
-    { std::vector<int> fill(cptr.begin(), cptr.end() - 1); for (int i = 0; i < N; i++) if (parent[i] >= 0) cidx[fill[parent[i]]++] = i; }
-    std::vector<int> stack; stack.push_back(root);
+    std::vector<int> &stack = visit_stack; stack.clear(); stack.push_back(root);
     while (!stack.empty()) {
         const int n = stack.back(); stack.pop_back();
         bool update = true;
@@ -216,7 +249,7 @@ void RefModel::plan_visit(std::vector<Visit> &out) {
         else update = false;
         out.push_back({ n, update });
         if (!update) continue;                       // :769 returns before the children
-        for (int k = cptr[n]; k < cptr[n + 1]; k++) stack.push_back(cidx[k]);
+        for (int k : kids[n]) stack.push_back(k);
     }
 }
 // relinearisation counter over the visited poses (aprilsam.c:741-751)

@@ -159,13 +159,18 @@ struct PatchList {
         hdr.push_back(Patch{ dst, (long long)off, (long long)bytes });
         used = off + bytes;
     }
-    // appends the header behind the payload and launches the scatter kernel (nothing to do: no launch)
+    // appends the header behind the payload; returns it (pinned memory the kernels read across PCIe)
+    const Patch *finish() {
+        const size_t hoff = (used + 63) & ~(size_t)63, hbytes = hdr.size() * sizeof(Patch);
+        buf.need(hoff + hbytes + 64, true);
+        memcpy(buf.p + hoff, hdr.data(), hbytes);
+        return (const Patch *)(buf.p + hoff);
+    }
+    // ... and launches the scatter kernel (nothing to do: no launch)
     void launch(hipStream_t s) {
         if (hdr.empty()) return;
-        const size_t hoff = (used + 63) & ~(size_t)63, hbytes = hdr.size() * sizeof(Patch);
-        buf.need(hoff + hbytes, true);
-        memcpy(buf.p + hoff, hdr.data(), hbytes);
-        hipLaunchKernelGGL(k_apply_patches, dim3((unsigned)hdr.size()), dim3(TPB), 0, s, (const Patch *)(buf.p + hoff), (const char *)buf.p);
+        const Patch *h = finish();
+        hipLaunchKernelGGL(k_apply_patches, dim3((unsigned)hdr.size()), dim3(TPB), 0, s, h, (const char *)buf.p);
     }
     void release() { buf.release(); hdr.clear(); used = 0; }
 };
@@ -775,7 +780,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.d_swap.need((size_t)P.F + INC_FACT_); c.d_pos.need((size_t)P.N + INC_NODES_);
     HIPCHECK(hipMemcpyAsync(c.d_swap.p, P.fac_swap.data(), P.F, hipMemcpyHostToDevice, s));
     HIPCHECK(hipMemcpyAsync(c.d_pos.p, P.pos.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
-    c.d_perm.need((size_t)P.N);
+    c.d_perm.need((size_t)P.N + INC_NODES_);
     HIPCHECK(hipMemcpyAsync(c.d_perm.p, P.perm.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
 
     // ---- launch tables -------------------------------------------------------------------------------------
@@ -1393,7 +1398,8 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         lev_dirty[I.f_level[t]].push_back(t);
     }
     if (I.i32_used + (long long)st_i32.size() > (long long)c.d_i32.cap || I.dest_used + (long long)st_dest.size() > (long long)c.d_dest.cap ||
-        I.child_used + (long long)st_child.size() > (long long)c.d_child.cap || (size_t)9 * I.slots_used > c.d_H.cap || (size_t)nFr > c.d_fd.cap) return false;
+        I.child_used + (long long)st_child.size() > (long long)c.d_child.cap || (size_t)9 * I.slots_used > c.d_H.cap || (size_t)nFr > c.d_fd.cap ||
+        (size_t)N > c.d_perm.cap) return false;
     // ---- 3. launch tables of the dirty fronts (transient region behind the base tables) + back-substitution lists -----
     std::vector<int> &tab = I.st_tab; tab.clear(); std::vector<LevelPlan> dl(nLev);
     auto dims = [&](int t, int *nsb, int *nub) { *nsb = nsb_of(t); *nub = I.cur_nub[t]; };
@@ -1504,6 +1510,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         ids.resize(N - Nold); zeros.assign(N - Nold, 0.0);
         for (int i = Nold; i < N; i++) ids[i - Nold] = i;
         PL.add(c.d_pos.p + Nold, ids.data(), ids.size() * 4);
+        PL.add(c.d_perm.p + Nold, ids.data(), ids.size() * 4);          // (tail poses are eliminated in id order: position = id)
         if (!batch) PL.add(c.d_lambda.p + Nold, zeros.data(), zeros.size() * 8);      // no Tikhonov term on poses added incrementally (aprilsam.c:508-542)
         c.lambda_N = -1;
         P.perm.resize(N); P.pos.resize(N);
@@ -1519,18 +1526,24 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         for (int i = 0; i < nT; i++) I.st_ids[i] = I.nLev0 + i;
         PL.add(c.d_flevel.p + nF0, I.st_ids.data(), (size_t)nT * 4);
     }
-    PL.launch(s);
-    if (batch) hipLaunchKernelGGL(k_load_states, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.d_state.p, gp.d_lp.p);      // l_point <- state
-    else hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
     // ---- 5. numeric: new factors linearised, dirty fronts level by level, back substitution, update ----------------------
     set_small_attr();
-    if (batch)
+    if (batch) {
+        PL.launch(s);
+        hipLaunchKernelGGL(k_load_states, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.d_state.p, gp.d_lp.p);      // l_point <- state
         hipLaunchKernelGGL((k_linearize_t<false>), dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                            gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, (const double *)nullptr,
                            nFr, c.d_flevel.p, 1, mp ? c.d_flags.p : (int *)nullptr);
-    else if (F > Fold)
-        hipLaunchKernelGGL((k_linearize_t<false>), dim3((F - Fold + TPB - 1) / TPB), dim3(TPB), 0, s, Fold, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);      // new priors: at the node's current state
+    } else {
+        // states first (the new factors are linearised at them; new priors at the node's current state), then ONE single-workgroup
+        // launch for all table patches + the linearisation of the new factors
+        hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
+        if (!PL.hdr.empty() || F > Fold) {
+            const Patch *hdr = PL.finish();
+            hipLaunchKernelGGL(k_inc_prologue, dim3(1), dim3(1024), 0, s, hdr, (const char *)PL.buf.p, (int)PL.hdr.size(), Fold, F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
+                               gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
+        }
+    }
     for (int l = 0; l < nLev; l++) {
         if (lev_dirty[l].empty()) continue;
         if (mp && l >= 1) {
@@ -1551,6 +1564,11 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     }
     if (mp && g_opt.wave_backsolve && mp_dn_maxns <= BSW_MAX_NS) hipLaunchKernelGGL(k_backsolve_w, dim3(mp_n), dim3(TPB), mp_dn_lds, s, c.dp, c.d_tab.p + mp_dn_off, c.d_pool.p, c.d_x.p, c.d_flags.p + nFr, c.d_bad.p, UpdArgs{});
     else if (mp) hipLaunchKernelGGL((k_backsolve_t<true>), dim3(mp_n), dim3(TPB), mp_dn_lds, s, c.dp, c.d_tab.p + mp_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + nFr, 1, c.d_bad.p, UpdArgs{});
+    // incremental steps: the state update (state = l_point + dx, pinned mirrors of state / dx / failure record) rides on the
+    // back substitution of the front that owns the pose -- every visited pose lives in a front of this sweep -- instead of
+    // a launch of its own over all poses
+    const UpdArgs upd = batch ? UpdArgs{} : UpdArgs{ c.d_perm.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p, gp.h_state.p, gp.h_dx.p, c.h_bad.p };
+    bool rode = false;
     for (int l = nLev - 1; l >= 0; l--) {
         if (mp && l >= 1) continue;
         if (batch) { launch_backsolve(c, dl[l], s, [](int) {}, []() {}); continue; }
@@ -1558,17 +1576,20 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             if (bs_n[l] > 0) {
                 const size_t lds = l >= I.nLev0 ? solve_lds_of(nF0 + l - I.nLev0) : I.base_levels[l].solve_lds;
                 if (g_opt.wave_backsolve && bs_maxns[l] <= BSW_MAX_NS && bs_wlds[l] <= 160 * 1024)      // a few fronts per level: latency is all that counts
-                    hipLaunchKernelGGL(k_backsolve_w, dim3((unsigned)bs_n[l]), dim3(TPB), bs_wlds[l], s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, (int *)nullptr, (int *)nullptr, UpdArgs{});
+                    hipLaunchKernelGGL(k_backsolve_w, dim3((unsigned)bs_n[l]), dim3(TPB), bs_wlds[l], s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, (int *)nullptr, c.d_bad.p, upd);
                 else
-                hipLaunchKernelGGL((k_backsolve_t<false>), dim3((unsigned)bs_n[l]), dim3(TPB), lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr, UpdArgs{});
+                    hipLaunchKernelGGL((k_backsolve_t<false>), dim3((unsigned)bs_n[l]), dim3(TPB), lds, s, c.dp, c.d_tab.p + bs_off[l], c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, c.d_bad.p, upd);
+                rode = true;
             }
         } else {                                     // every pose is visited: all base fronts, level by level
             const LevelPlan &L = I.base_levels[l];
-            hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, (int *)nullptr, UpdArgs{});
+            hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, c.d_tab.p + L.all_off, c.d_pool.p, c.d_x.p, 0, (int *)nullptr, 0, c.d_bad.p, upd);
+            rode = true;
         }
     }
-    hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
-                       batch ? gp.h_lp.p : gp.h_state.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);          // new states / dx / pivot flag straight into the pinned mirrors
+    if (batch || !rode)
+        hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
+                           batch ? gp.h_lp.p : gp.h_state.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);          // new states / dx / pivot flag straight into the pinned mirrors
     HIPCHECK(hipGetLastError());
     for (int t : fd_dirty) I.dirty[t] = 0;
     // the pattern folded into the device structures (a later batch call compares against it)
@@ -1780,6 +1801,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     std::vector<RefModel::Visit> &visits = c.visits;
     c.model.plan_visit(visits);                      // structural: which poses the reference's solve_node touches
     const bool partial = c.model.naffected <= 5;     // aprilsam.c:755: otherwise the whole tree is walked
+    c.h_bad.p[0] = c.h_bad.p[1] = c.h_bad.p[2] = c.h_bad.p[3] = 0;      // (the riding state update only ever writes a SET failure record)
     bool reused = g_opt.inc_fast && gp.host_idx.empty() && inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, partial ? &visits : nullptr);
     if (!reused) {                // the step does not fit the frozen structure (or slack ran out): full re-plan
         upload_factors(gp);

@@ -386,6 +386,7 @@ void  aprilsam_amd_refmodel_batch(void *m, int n_nodes, int n_factors, const int
 int   aprilsam_amd_refmodel_inc_begin(void *m, int n_nodes, int n_factors, const int *fa, const int *fb);   /* -> naffected */
 int   aprilsam_amd_refmodel_solve_visit(void *m, const double *x, double dxy, double dth, int *visited);    /* -> start_over */
 void  aprilsam_amd_refmodel_get(void *m, int *parent, int *changed, int *relin);
+int   aprilsam_amd_refmodel_check(void *m);   /* 0: the incrementally maintained tree equals a full recomputation */
 
 /* ---- synthetic Manhattan lattice generator ----------------------- */
 /* Appends K*K xyt nodes, the in-bounds 4-direction xyt factors and the node-0 prior to `graph`.

@@ -113,3 +113,42 @@ def test_incremental_bookkeeping_follows_the_reference_step_by_step(lib, reflib,
     assert fallbacks == [232]                                # first fall-back at 232 nodes
     lib.dll.aprilsam_amd_refmodel_destroy(M)
     p.destroy(); g.destroy()
+
+
+def test_incrementally_maintained_tree_equals_a_full_recomputation(lib):
+    """RefModel keeps the block elimination tree up to date by merging root paths per new edge (refmodel.cpp insert_edge)
+    instead of recomputing it from the whole graph at every incremental step: random growth -- new poses with odometry, loop
+    closures to old poses, several factors per step, duplicates, factors between two OLD poses, priors -- must leave exactly
+    the tree (and children lists) a recomputation gives."""
+    d = lib.dll
+    d.aprilsam_amd_refmodel_create.restype = C.c_void_p
+    d.aprilsam_amd_refmodel_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, ip]
+    d.aprilsam_amd_refmodel_inc_begin.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, ip]
+    d.aprilsam_amd_refmodel_check.argtypes = [C.c_void_p]
+    d.aprilsam_amd_refmodel_solve_visit.argtypes = [C.c_void_p, dp, C.c_double, C.c_double, ip]
+    d.aprilsam_amd_refmodel_destroy.argtypes = [C.c_void_p]
+    for seed in range(6):
+        rng = np.random.default_rng(seed)
+        n0 = int(rng.integers(1, 60))
+        st, fa, fb, z, W = datasets.random_pose_graph(max(n0, 2), int(rng.integers(0, 40)), seed)
+        fa, fb = list(map(int, fa)), list(map(int, fb))
+        N = len(st)
+        M = C.c_void_p(d.aprilsam_amd_refmodel_create())
+        a = np.array(fa, np.int32); b = np.array(fb, np.int32)
+        d.aprilsam_amd_refmodel_batch(M, N, len(a), _i(a), _i(b))
+        assert d.aprilsam_amd_refmodel_check(M) == 0
+        for step in range(120):
+            for _ in range(int(rng.integers(0, 3))):
+                fa.append(N - 1); fb.append(N); N += 1                       # a new pose with its odometry factor
+            for _ in range(int(rng.integers(0, 4))):
+                u, v = int(rng.integers(0, N)), int(rng.integers(0, N))
+                if u != v:
+                    fa.append(u); fb.append(v)                               # anything to anything: closures, old-old, duplicates
+            if rng.random() < 0.1:
+                fa.append(int(rng.integers(0, N))); fb.append(-1)            # a prior
+            a = np.array(fa, np.int32); b = np.array(fb, np.int32)
+            d.aprilsam_amd_refmodel_inc_begin(M, N, len(a), _i(a), _i(b))
+            assert d.aprilsam_amd_refmodel_check(M) == 0, (seed, step)
+            x = np.zeros(3 * N); vis = np.zeros(N, np.int32)
+            d.aprilsam_amd_refmodel_solve_visit(M, x.ctypes.data_as(dp), 0.1, 0.1, _i(vis))     # clears the labels like a real step
+        d.aprilsam_amd_refmodel_destroy(M)
