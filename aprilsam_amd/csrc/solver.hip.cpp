@@ -82,6 +82,7 @@ static void load_env_options() {
         v = g_opt.wave_backsolve; envd("APRILSAM_AMD_WAVE_BACKSOLVE", &v); g_opt.wave_backsolve = (int)v;
         v = g_opt.left_panels; envd("APRILSAM_AMD_LEFT_PANELS", &v); g_opt.left_panels = (int)v;
         v = g_opt.block_panels; envd("APRILSAM_AMD_BLOCK_PANELS", &v); g_opt.block_panels = (int)v;
+        v = g_opt.blk_backsolve; envd("APRILSAM_AMD_BLK_BACKSOLVE", &v); g_opt.blk_backsolve = (int)v;
         v = g_opt.batch_extend; envd("APRILSAM_AMD_BATCH_EXTEND", &v); g_opt.batch_extend = (int)v;
         v = g_opt.extend_tail_fronts; envd("APRILSAM_AMD_EXTEND_TAIL_FRONTS", &v); g_opt.extend_tail_fronts = (int)v;
         v = g_opt.mem_cap_mb; envd("APRILSAM_AMD_MEM_CAP_MB", &v); g_opt.mem_cap_mb = (int)v;
@@ -413,6 +414,8 @@ struct LevelPlan {
     int all_off = 0, n_all = 0; size_t solve_lds = 0;          // every front (k_backsolve)
     size_t solve_w_lds = 0; int maxns = 0;                     // ... in the column-per-lane form (k_backsolve_w: L panel in LDS), widest own part
     Launch bs_gemv{};                                          // fronts whose update-row product is spread over workgroups first (k_backsolve_gemv)
+    Launch bs_blk{}; size_t bs_blk_lds = 0;                    // wide fronts back-substituted by a chain + helper workgroups (k_backsolve_blk); grid 0: none
+    int rest_off = 0, n_rest = 0; size_t rest_lds = 0;         // ... and the level's other fronts (k_backsolve_t)
 };
 
 // state of the incremental fast path (inc_fast.*): the plan of the last batch step stays frozen, poses added since
@@ -496,6 +499,7 @@ struct Context {
     int persist_l0 = -1;                  // first level of the multi-level launch, -1: none
     int p_up_off = 0, p_up_n = 0, p_dn_off = 0, p_dn_n = 0, p_nt = 1024; size_t p_up_lds = 0, p_dn_lds = 0; long long p_up_full = 0; int p_dn_maxns = 0;
     DBuf<int> d_flags, d_flevel, d_perm;
+    DBuf<double> d_dinv, d_bsb_far; DBuf<int> d_bsb_flags;   // inverse diagonal blocks of the big fronts; scratch of k_backsolve_blk
     DBuf<int> d_solve_tab; std::vector<int> solve_tab;      // april_graph_cholesky_inc_solver: front lists of its back substitution
     hipGraphExec_t gexec = nullptr;
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
@@ -506,7 +510,7 @@ struct Context {
     double lambda_val = -1; int lambda_N = -1;     // what d_lambda currently holds (uniform batch value), -1: unknown
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
-        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release(); d_flags.release(); d_flevel.release(); d_perm.release(); d_solve_tab.release();
+        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release(); d_flags.release(); d_flevel.release(); d_perm.release(); d_solve_tab.release(); d_dinv.release(); d_bsb_far.release(); d_bsb_flags.release();
         if (gexec) (void)hipGraphExecDestroy(gexec);
         gexec = nullptr;
         if (gexec_api) (void)hipGraphExecDestroy(gexec_api);
@@ -614,8 +618,9 @@ static size_t diag_doubles(int n_big, int n_diag_slots) {
     return std::max((size_t)(std::max(n_big, n_diag_slots) + 64) * NB * (NB + 1), (size_t)std::max(n_big, 1) * OBP * NB * NB);
 }
 // classify the fronts of one level (small / big) and append their launch tables to `tab`
-template <class Dims>
-static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int> &tab, Dims dims) {
+constexpr int BSB_MAX_WGS = 64;               // chain + helper workgroups of one k_backsolve_blk launch (they must be resident together)
+template <class Dims, class KeepInv>
+static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int> &tab, Dims dims, KeepInv keep_inv) {
     const size_t small_max = (size_t)g_opt.small_lds_kb * 1024;
     L = LevelPlan();
     std::vector<int> small, big;
@@ -670,6 +675,31 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
         return La;
     };
     L.asm_big = make((int)big.size(), [&](int t) { return asm_chunks(cols(t) / 3); });
+    {   // back substitution of the multi-workgroup fronts 128 columns at a time (k_backsolve_blk): fronts whose inverse
+        // diagonal blocks are kept (keep_inv) and whose update-row product comes from k_backsolve_gemv (or is empty);
+        // the whole level or nothing: chains + helpers must fit BSB_MAX_WGS workgroups
+        std::vector<int> wide, rest, bigs(big);
+        std::sort(bigs.begin(), bigs.end());
+        int wgs = 0;
+        for (int t : fronts) {
+            int a, b; dims(t, &a, &b);
+            const bool isbig = std::binary_search(bigs.begin(), bigs.end(), t);
+            if (isbig && 3 * a <= BSB_FAR && (b == 0 || bs_split_front(a, b)) && keep_inv(t)) { wide.push_back(t); wgs += 1 + bsb_helpers(3 * a); }
+            else rest.push_back(t);
+        }
+        if (!wide.empty() && wgs <= BSB_MAX_WGS && g_opt.block_panels && g_opt.blk_backsolve) {
+            const int lo = (int)tab.size();
+            tab.insert(tab.end(), wide.begin(), wide.end());
+            L.bs_blk = Launch{ lo, (int)tab.size(), (int)wide.size(), 0, false };
+            int acc = 0; tab.push_back(0);
+            for (int t : wide) { acc += 1 + bsb_helpers(3 * nsb_of(t)); tab.push_back(acc); L.bs_blk_lds = std::max(L.bs_blk_lds, bsb_lds(3 * nsb_of(t))); }
+            L.bs_blk.grid = acc;
+            L.rest_off = (int)tab.size(); L.n_rest = (int)rest.size();
+            tab.insert(tab.end(), rest.begin(), rest.end());
+            size_t mm = 0; for (int t : rest) mm = std::max<size_t>(mm, cols(t));
+            L.rest_lds = (mm + NB + 8 + NB * (NB + 1)) * 8;
+        }
+    }
     int steps = (3 * nsb_of(big[0]) + NB - 1) / NB;
     auto active = [&](int sidx) { int nact = 0; while (nact < (int)big.size() && 3 * nsb_of(big[nact]) > sidx * NB) nact++; return nact; };
     std::vector<int> wb;
@@ -788,7 +818,19 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.levels.assign(P.nLevels, LevelPlan());
     for (int l = 0; l < P.nLevels; l++) {
         std::vector<int> fr(P.lev_fronts.begin() + P.lev_ptr[l], P.lev_fronts.begin() + P.lev_ptr[l + 1]);
-        build_level(c.levels[l], fr, tab, [&](int t, int *nsb, int *nub) { *nsb = P.f_nsb[t]; *nub = P.f_nub[t]; });
+        build_level(c.levels[l], fr, tab, [&](int t, int *nsb, int *nub) { *nsb = P.f_nsb[t]; *nub = P.f_nub[t]; }, [](int) { return true; });
+    }
+    {   // persistent inverse diagonal blocks of the multi-workgroup fronts (k_block_chain leaves them, k_block_solve and
+        // k_backsolve_blk use them): whole outer blocks per front
+        long long slots = 0;
+        for (int t = 0; t < P.nF; t++) fd[t].dinv0 = -1;
+        for (int l = 0; l < P.nLevels; l++) {
+            const LevelPlan &L = c.levels[l];
+            for (int k = 0; k < L.asm_big.n; k++) { const int t = tab[L.asm_big.list_off + k]; fd[t].dinv0 = (int)slots; slots += (long long)OBP * bsb_blocks(3 * P.f_nsb[t]); }
+        }
+        c.d_dinv.need((size_t)std::max<long long>(slots, 1) * NB * NB);
+        HIPCHECK(hipMemcpyAsync(c.d_fd.p, fd.data(), fd.size() * sizeof(FrontDesc), hipMemcpyHostToDevice, s));
+        if (!c.d_bsb_flags.p) { c.d_bsb_flags.need((size_t)BSB_MAX_WGS * 2 * BSB_MAXB); HIPCHECK(hipMemsetAsync(c.d_bsb_flags.p, 0, c.d_bsb_flags.cap * 4, s)); c.d_bsb_far.need((size_t)BSB_MAX_WGS * BSB_FAR); }
     }
     for (int l = 0; l < P.nLevels; l++)
         if (c.levels[l].solve_lds > 160 * 1024)       // k_backsolve keeps x over a front's rows in LDS (~19 000 scalar rows)
@@ -851,6 +893,7 @@ static void set_small_attr() {
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_w, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_block_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_block_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_block_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
@@ -865,13 +908,21 @@ static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic 
     if (L.bs_gemv.grid > 0)
         hipLaunchKernelGGL(k_backsolve_gemv, dim3(L.bs_gemv.grid), dim3(TPB), 0, s, c.dp, tab + L.bs_gemv.list_off, tab + L.bs_gemv.pre_off,
                            L.bs_gemv.n, c.d_pool.p, c.d_x.p);
+    // wide fronts: chain + helper workgroups (k_backsolve_blk); the level's other fronts below
+    int n_all = L.n_all, all_off = L.all_off; size_t solve_lds = L.solve_lds;
+    if (L.bs_blk.grid > 0) {
+        hipLaunchKernelGGL(k_backsolve_blk, dim3(L.bs_blk.grid), dim3(TPB), L.bs_blk_lds, s, c.dp, tab + L.bs_blk.list_off, tab + L.bs_blk.pre_off, L.bs_blk.n,
+                           c.d_pool.p, c.d_x.p, c.d_dinv.p, c.d_bsb_flags.p, c.d_bsb_far.p, L.bs_gemv.grid > 0 ? 1 : 0, c.d_bad.p, upd);
+        n_all = L.n_rest; all_off = L.rest_off; solve_lds = L.rest_lds;
+        if (!n_all) { toc(); return; }
+    }
     // latency-bound levels of small fronts: column-per-lane form with the L panel in LDS (at least two workgroups per CU)
     if (g_opt.wave_backsolve && L.bs_gemv.grid == 0 && L.n_all < g_opt.tp_fronts && L.maxns <= BSW_MAX_NS && L.solve_w_lds <= 80 * 1024)
-        hipLaunchKernelGGL(k_backsolve_w, dim3(L.n_all), dim3(TPB), L.solve_w_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, (int *)nullptr, c.d_bad.p, upd);
-    else if (L.solve_lds >= (size_t)(BS_TALL_ROWS + NB + 8 + NB * (NB + 1)) * 8)
-        hipLaunchKernelGGL((k_backsolve_t<false, true>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, c.d_bad.p, upd);
+        hipLaunchKernelGGL(k_backsolve_w, dim3(n_all), dim3(TPB), L.solve_w_lds, s, c.dp, tab + all_off, c.d_pool.p, c.d_x.p, (int *)nullptr, c.d_bad.p, upd);
+    else if (solve_lds >= (size_t)(BS_TALL_ROWS + NB + 8 + NB * (NB + 1)) * 8)
+        hipLaunchKernelGGL((k_backsolve_t<false, true>), dim3(n_all), dim3(TPB), solve_lds, s, c.dp, tab + all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, c.d_bad.p, upd);
     else
-        hipLaunchKernelGGL((k_backsolve_t<false>), dim3(L.n_all), dim3(TPB), L.solve_lds, s, c.dp, tab + L.all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, c.d_bad.p, upd);
+        hipLaunchKernelGGL((k_backsolve_t<false>), dim3(n_all), dim3(TPB), solve_lds, s, c.dp, tab + all_off, c.d_pool.p, c.d_x.p, L.bs_gemv.grid > 0 ? 1 : 0, (int *)nullptr, 0, c.d_bad.p, upd);
     toc();
 }
 
@@ -919,10 +970,10 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
         for (size_t o = 0; o < L.bchain.size(); o++) {
             const Launch &bc = L.bchain[o], &bt = L.btile[o];
             tic(K_PANEL_BIG);
-            hipLaunchKernelGGL(k_block_chain, dim3(bc.n), dim3(BCH_THREADS), block_chain_lds(), s, c.dp, tab + bc.list_off, (int)o, c.d_pool.p, c.d_diag.p, c.d_bad.p);
+            hipLaunchKernelGGL(k_block_chain, dim3(bc.n), dim3(BCH_THREADS), block_chain_lds(), s, c.dp, tab + bc.list_off, (int)o, c.d_pool.p, c.d_diag.p, c.d_dinv.p, c.d_bad.p);
             if (bt.grid > 0) {
-                if (bt.tile == 2) hipLaunchKernelGGL(k_block_solve<2>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p);
-                else hipLaunchKernelGGL(k_block_solve<1>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p);
+                if (bt.tile == 2) hipLaunchKernelGGL(k_block_solve<2>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p, c.d_dinv.p);
+                else hipLaunchKernelGGL(k_block_solve<1>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p, c.d_dinv.p);
             }
             toc();
             const int k = std::min((int)(o + 1) * OBP, steps) - 1;      // the panel step that closes the outer block carries its wide update
@@ -1240,7 +1291,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             I.parent.push_back(-1); I.E.emplace_back(); I.xfac.emplace_back(); I.rel_begin.push_back(0); I.cur_nub.push_back(0); I.cur_cap.push_back(0);
             I.dirty.push_back(0); I.f_level.push_back(I.nLev0 + n_tail() - 1); I.kids.emplace_back();
             I.fd.emplace_back(); memset(&I.fd[t], 0, sizeof(FrontDesc));
-            I.fd[t].first = k; I.fd[t].parent = -1;
+            I.fd[t].first = k; I.fd[t].parent = -1; I.fd[t].dinv0 = -1;
         }
         I.t_cnt.back()++;
         I.tf_of.push_back(nF0 + n_tail() - 1);
@@ -1409,7 +1460,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             else lev_dirty[l].assign(1, nF0 + l - I.nLev0);
         }
     }
-    for (int l = 0; l < nLev; l++) if (!lev_dirty[l].empty()) build_level(dl[l], lev_dirty[l], tab, dims);
+    for (int l = 0; l < nLev; l++) if (!lev_dirty[l].empty()) build_level(dl[l], lev_dirty[l], tab, dims, [&](int t) { return I.fd[t].dinv0 >= 0; });
     // back substitution: tail fronts one by one (last first), then the base levels; restricted to the fronts that hold a
     // visited pose (and their ancestors) when the reference only walks the marked root paths
     I.need.assign(nFr, needed ? 0 : 1);
@@ -1446,6 +1497,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         for (auto &x : L.syrkb) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.bchain) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.btile) { x.list_off += sh; x.pre_off += sh; }
+        L.bs_blk.list_off += sh; L.bs_blk.pre_off += sh; L.rest_off += sh;
         L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh; L.wb_off += sh;
         if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
     }
@@ -2466,7 +2518,7 @@ static int shard_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *para
     for (int l = 0; l < P.nLevels; l++) {
         std::vector<int> fr;
         for (int k = P.lev_ptr[l]; k < P.lev_ptr[l + 1]; k++) if (S.owner[P.lev_fronts[k]] == rank) fr.push_back(P.lev_fronts[k]);
-        build_level(S.levels[l], fr, tab, [&](int t, int *nsb, int *nub) { *nsb = P.f_nsb[t]; *nub = P.f_nub[t]; });
+        build_level(S.levels[l], fr, tab, [&](int t, int *nsb, int *nub) { *nsb = P.f_nsb[t]; *nub = P.f_nub[t]; }, [&](int t) { return c.inc.fd[t].dinv0 >= 0; });
     }
     if (tab.empty()) tab.push_back(0);
     S.d_tab.need(tab.size());
@@ -2846,6 +2898,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "wave_backsolve") g_opt.wave_backsolve = (int)v;
     else if (k == "left_panels") g_opt.left_panels = (int)v;
     else if (k == "block_panels") g_opt.block_panels = (int)v;
+    else if (k == "blk_backsolve") g_opt.blk_backsolve = (int)v;
     else if (k == "batch_extend") g_opt.batch_extend = (int)v;
     else if (k == "extend_tail_fronts") g_opt.extend_tail_fronts = (int)v;
     else if (k == "mem_cap_mb") g_opt.mem_cap_mb = (int)v;
