@@ -91,7 +91,7 @@ def pmc_traffic(pmc, kernel):
 
 
 # rocprofv3 kernel names of the K_BACKSOLVE / K_PANEL_BIG slots (several kernels share a slot)
-PMC_NAMES = {"k_backsolve": ("k_backsolve_t", "k_backsolve_w", "k_backsolve_gemv"), "k_panel_big": ("k_diagpanel_ll", "k_front_chain")}
+PMC_NAMES = {"k_backsolve": ("k_backsolve_blk", "k_backsolve_t", "k_backsolve_w", "k_backsolve_gemv"), "k_panel_big": ("k_block_chain", "k_block_solve", "k_diagpanel_ll")}
 
 
 def hbm_rooflines(prof, iters, pmc_file=None, survey_bytes=None):

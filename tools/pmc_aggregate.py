@@ -54,6 +54,25 @@ if hbm:
                        "values are RAW, bench.py applies the x2 to the read side", "counters": hbm},
               open(os.path.join(dst, f"{tag}_pmc_hbm.json"), "w"), indent=1)
     print("wrote", f"{tag}_pmc_hbm.json")
+for suffix, label, out in (("lat316", "python tools/lattice_big.py 316 2 (100k-pose lattice, config 4)", f"{tag}_pmc_hbm_lattice100k.json"),
+                           ("lat1000", "python tools/lattice_big.py 1000 1 (1M-pose lattice, config 5)", f"{tag}_pmc_hbm_lattice1m.json")):
+    hb = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        r = counters(f"pmc_{c}_{suffix}")
+        if r and c in r:
+            hb[c] = {k: {"dispatches": v["dispatches"], "total_kb": v["total"], "kb_per_dispatch": v["per_dispatch"]} for k, v in r[c].items()}
+    if hb:
+        json.dump({"source_hash": SRC_HASH, "command": "APRILSAM_AMD_USE_GRAPH=0 rocprofv3 --pmc <COUNTER> --output-format csv -- " + label + ", one pass per counter",
+                   "unit": "KB as reported by rocprofv3, RAW; bench.py applies the gfx950 x2 on the read side (MI355X_MICROARCH.md)", "counters": hb},
+                  open(os.path.join(dst, out), "w"), indent=1)
+        print("wrote", out)
+try:
+    b = json.loads(open(os.path.join(src, "bench_cpu_lattice100k.json")).read().strip().splitlines()[-1])
+    rc = b["lattice100k"]["reference_cpu_same_host"]
+    json.dump({k: rc[k] for k in ("s_per_iter", "cores", "chi2_after_1", "host")}, open(os.path.join(dst, f"{tag}_cpu_lattice100k.json"), "w"), indent=1)
+    print("wrote", f"{tag}_cpu_lattice100k.json")
+except Exception as e:
+    print("no cpu lattice100k record:", repr(e))
 for sub, label, out in (("pmc_mfma", "python tools/lattice_big.py 316 2   (100k-pose lattice, config 4", f"{tag}_pmc_mfma.json"),
                         ("pmc_mfma1m", "python tools/lattice_big.py 1000 1   (1M-pose lattice, config 5", f"{tag}_pmc_mfma_lattice1m.json")):
     m = counters(sub)
@@ -72,6 +91,6 @@ for sub, label, out in (("pmc_mfma", "python tools/lattice_big.py 316 2   (100k-
                           "-- " + label + "; sums over all dispatches of the run)",
                "kernels": per}, open(os.path.join(dst, out), "w"), indent=1)
     print("wrote", out)
-for f in ("ubench_mfma_f64.txt", "ubench_valu_lat.txt"):
+for f in ("ubench_mfma_f64.txt", "ubench_valu_lat.txt", "chain_times_lattice100k.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}")); print("wrote", f"{tag}_{f}")

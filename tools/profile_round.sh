@@ -4,7 +4,7 @@
 # Outputs under gpurun_out/prof_<tag>/ ; tools/pmc_aggregate.py turns them into the files kept in profiles/.
 # Counter passes are separate runs (one --pmc set each, no trace domains besides the kernel trace), without hipGraph
 # replay (counter collection over graph replays does not terminate on ROCm 7.2) and each under its own timeout.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -23,6 +23,16 @@ APRILSAM_AMD_USE_GRAPH=0 timeout 200 rocprofv3 --kernel-trace --stats --output-f
 # config 5 on one GPU (1M poses): kernel stats + MFMA counters of the wide-supernode path
 APRILSAM_AMD_USE_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lattice1m -- python $ROOT/tools/lattice_big.py 1000 1 > $OUT/stats_lattice1m.log 2>&1
 APRILSAM_AMD_USE_GRAPH=0 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma1m -- python $ROOT/tools/lattice_big.py 1000 1 > $OUT/pmc_mfma1m.log 2>&1
+# HBM traffic of the bandwidth-bound kernels on the lattices (k_linearize, k_assemble_big, k_backsolve_*): FETCH_SIZE / WRITE_SIZE,
+# one pass per counter and workload
+for C in FETCH_SIZE WRITE_SIZE; do
+  APRILSAM_AMD_USE_GRAPH=0 timeout 200 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_lat316 -- $LAT > $OUT/pmc_${C}_lat316.log 2>&1
+  APRILSAM_AMD_USE_GRAPH=0 timeout 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_lat1000 -- python $ROOT/tools/lattice_big.py 1000 1 > $OUT/pmc_${C}_lat1000.log 2>&1
+done
+# phase stamps of the outer-block chain kernel (root front of the 100k lattice)
+timeout 120 python $ROOT/tools/chain_times.py 316 > $OUT/chain_times_lattice100k.txt 2>&1
+# the reference CPU on the 100k lattice on THIS host: one april_graph_cholesky call (about a minute, one core)
+timeout 400 python $ROOT/bench.py --steps 20 --warmup 3 --no-inc --no-cpu-baseline --lattice1m-k 0 --cpu-lattice100k > $OUT/bench_cpu_lattice100k.json 2> $OUT/bench_cpu_lattice100k.err
 # config 3: the incremental demo (first 1500 poses)
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_inc -- python $ROOT/tools/inc_demo.py 1500 > $OUT/stats_inc.log 2>&1
 # instruction-rate micro-benchmarks the roofline discussion quotes

@@ -3,8 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef double d4 __attribute__((ext_vector_type(4)));
+// clk[0..1]: shader-clock ticks (s_memtime) and constant 100 MHz ticks (s_memrealtime) spent inside the kernel by workgroup 0:
+// their ratio is the clock the compute units actually ran at UNDER THIS LOAD -- the "cycles per instruction" below use it
 template <int NACC>
-__global__ void __launch_bounds__(256) k_mfma(double *out, int iters, double a0, double b0) {
+__global__ void __launch_bounds__(256) k_mfma(double *out, int iters, double a0, double b0, long long *clk = nullptr) {
+    const long long c0 = clock64(), w0 = wall_clock64();
     d4 acc[NACC];
     for (int i = 0; i < NACC; i++) acc[i] = (d4){ 0, 0, 0, 0 };
     double a = a0 + threadIdx.x * 1e-9, b = b0;
@@ -15,6 +18,7 @@ __global__ void __launch_bounds__(256) k_mfma(double *out, int iters, double a0,
     double s = 0;
     for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678) out[0] = s;
+    if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
 }
 template <int NACC>
 __global__ void __launch_bounds__(256) k_fma(double *out, int iters, double a0, double b0) {
@@ -38,13 +42,17 @@ int main() {
     double *out; hipMalloc(&out, 8);
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount, iters = 20000;
-    printf("%s: %d CUs, %d MHz\n", p.gcnArchName, cus, p.clockRate / 1000);
+    printf("%s: %d CUs, %d MHz (device property)\n", p.gcnArchName, cus, p.clockRate / 1000);
+    long long *clk; hipMalloc(&clk, 16); long long hclk[2];
     for (int wpc = 1; wpc <= 2; wpc++) {                     // workgroups of 4 waves per CU
         const int grid = cus * wpc;
-        float ms = timeit([&] { hipLaunchKernelGGL(k_mfma<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0, 1.0); });
+        float ms = timeit([&] { hipLaunchKernelGGL(k_mfma<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0, 1.0, clk); });
+        hipMemcpy(hclk, clk, 16, hipMemcpyDeviceToHost);
+        const double mhz = 100.0 * (double)hclk[0] / (double)hclk[1];      // measured shader clock under FP64 MFMA load
         double n = (double)grid * 4 * iters * 4;               // MFMA instructions
-        printf("mfma_f64_16x16x4 x4 acc, %d WG/CU: %.3f ms  %.2f TFLOP/s  %.1f cycles/instr/SIMD @2.4GHz\n", wpc, ms, n * 2048 / ms / 1e9,
-               ms * 1e-3 * 2.4e9 / ((double)iters * 4 * wpc));
+        printf("mfma_f64_16x16x4 x4 acc, %d WG/CU: %.3f ms  %.2f TFLOP/s  measured clock %.0f MHz (s_memtime / s_memrealtime)  %.1f cycles/instr/SIMD at that clock  "
+               "-> data-sheet rate (64 cycles/instr) at that clock would be %.1f TFLOP/s\n", wpc, ms, n * 2048 / ms / 1e9, mhz,
+               ms * 1e-3 * mhz * 1e6 / ((double)iters * 4 * wpc), 2048.0 * 4 * cus * mhz * 1e6 / 64 / 1e12);
         ms = timeit([&] { hipLaunchKernelGGL(k_mfma<16>, dim3(grid), dim3(256), 0, 0, out, iters / 4, 1.0, 1.0); });
         n = (double)grid * 4 * (iters / 4) * 16;
         printf("mfma_f64_16x16x4 x16 acc, %d WG/CU: %.3f ms  %.2f TFLOP/s\n", wpc, ms, n * 2048 / ms / 1e9);
