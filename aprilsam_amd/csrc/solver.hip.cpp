@@ -2568,6 +2568,19 @@ long long shard_info(const april_graph_cholesky_param_t *param, int what, long l
     else if (what == 1) v = S.xfer;
     else if (what == 2) v = S.bcast;
     else if (what == 3) v.assign(S.owner.begin(), S.owner.end());
+    else if (what == 4) {
+        // modelled critical path of this mapping, in sum c_j^2 flops: the fronts whose rank range spans more than one rank run one
+        // after the other on their owners (serial part); below them every rank works through its own subtrees in parallel
+        const Plan &P = ic->second->plan;
+        double total = 0, top = 0; std::vector<double> local(S.world, 0.0);
+        for (int t = 0; t < P.nF; t++) {
+            const double ns = 3.0 * P.f_nsb[t], nu = 3.0 * P.f_nub[t];
+            double fl = 0; for (int q = 0; q < (int)ns; q++) { const double cj = (ns - q) + nu + 1; fl += cj * cj; }
+            total += fl;
+            if (S.top[t]) top += fl; else local[S.owner[t]] += fl;
+        }
+        v = { (long long)total, (long long)top, (long long)*std::max_element(local.begin(), local.end()) };
+    }
     if (out) for (long long i = 0; i < (long long)v.size() && i < cap; i++) out[i] = v[i];
     return (long long)v.size();
 }

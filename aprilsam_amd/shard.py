@@ -134,6 +134,12 @@ class ShardedSolver:
                 "rccl_version": f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v else None, "librccl": path.value.decode() or None,
                 "hip_device": int(out[4])}
 
+    def modelled_speedup(self):
+        """bound on the speed-up of the factorisation under this mapping: fronts that span several ranks are serial (one owner each),
+        below them every rank works through its own subtrees (aprilsam_amd_shard_info what = 4)"""
+        total, top, local = (float(v) for v in self._info(4))
+        return {"flops_total": total, "flops_serial_top_fronts": top, "flops_busiest_rank_subtrees": local, "speedup_bound": total / max(top + local, 1.0)}
+
     def comm_bytes_per_iteration(self):
         return int(8 * (self.xfer[:, 5].sum() + 3 * self.bcast[:, 4].sum() * (self.world - 1)))
 

@@ -296,6 +296,7 @@ def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iter
         chi.append(sol.chi2())
         owned = int((sol.owner == rank).sum())
         res["comm"] = sol.comm_info()
+        res["modelled_critical_path"] = sol.modelled_speedup()
         res.update(parallelism=f"nested-dissection subtree shards x{world}, exchange inside the library ({'RCCL on the solver stream' if backend == 'nccl' else 'host callbacks over ' + backend})",
                    fronts=int(sol.n_fronts), fronts_owned_by_rank0=owned, schur_slabs_exchanged=int(len(sol.xfer)),
                    separator_broadcasts=int(len(sol.bcast)), comm_bytes_per_iteration=sol.comm_bytes_per_iteration(),

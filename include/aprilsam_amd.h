@@ -336,7 +336,9 @@ int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, doubl
  * No all-reduce on the data path; world = 1 needs no transport.
  *   shard_info what: 0 -> {levels, fronts, nodes, pool doubles of this rank, pool doubles of the whole plan};
  *                    1 -> transfers {level, front, src, dst, (unused), packed count in doubles};
- *                    2 -> broadcasts {level, front, owner, first position, blocks}; 3 -> owner rank per front
+ *                    2 -> broadcasts {level, front, owner, first position, blocks}; 3 -> owner rank per front;
+ *                    4 -> modelled critical path in sum c_j^2 flops {whole factorisation, fronts spanning several ranks (run one
+ *                         after the other), the busiest rank's own subtrees}: speed-up bound = [0] / ([1] + [2])
  * Return codes: 0 ok; -1 bad arguments / no shard_begin; -2 non-positive pivot; -4 foreign factor types; -5 librccl.so not
  * loadable; -6 communication error (RCCL or host callback; message on stderr); -7 no transport attached. */
 typedef struct aprilsam_amd_host_comm {
