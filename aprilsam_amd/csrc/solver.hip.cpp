@@ -83,6 +83,7 @@ static void load_env_options() {
         v = g_opt.left_panels; envd("APRILSAM_AMD_LEFT_PANELS", &v); g_opt.left_panels = (int)v;
         v = g_opt.block_panels; envd("APRILSAM_AMD_BLOCK_PANELS", &v); g_opt.block_panels = (int)v;
         v = g_opt.blk_backsolve; envd("APRILSAM_AMD_BLK_BACKSOLVE", &v); g_opt.blk_backsolve = (int)v;
+        v = g_opt.tile_assembly; envd("APRILSAM_AMD_TILE_ASSEMBLY", &v); g_opt.tile_assembly = (int)v;
         v = g_opt.batch_extend; envd("APRILSAM_AMD_BATCH_EXTEND", &v); g_opt.batch_extend = (int)v;
         v = g_opt.extend_tail_fronts; envd("APRILSAM_AMD_EXTEND_TAIL_FRONTS", &v); g_opt.extend_tail_fronts = (int)v;
         v = g_opt.mem_cap_mb; envd("APRILSAM_AMD_MEM_CAP_MB", &v); g_opt.mem_cap_mb = (int)v;
@@ -405,7 +406,7 @@ struct LevelPlan {
     long long full_limit = 0;                                  // ... fully in LDS when their array fits this many bytes, else panel mode
     int small_nt = 512;                                        // ... with this many threads per workgroup
     int n_big = 0; size_t asm_lds = 0;
-    Launch asm_big{};                                          // k_assemble_big
+    Launch asm_big{}, asm_tile{};                              // k_assemble_big (chunks of block columns) / k_assemble_tile (windows, option tile_assembly)
     std::vector<Launch> syrka, syrkb;                          // look-ahead split of the wide update (modes 2, 3), same indexing as syrkw
     std::vector<Launch> panel, syrk, syrkw;                    // per panel step: diag+panel, narrow update, wide update (grid 0 unless the step closes an outer block)
     std::vector<Launch> bchain, btile;                         // per outer block (option block_panels): diagonal-block workgroups, row tiles (Launch::tile = rows per wave / 16)
@@ -675,6 +676,7 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
         return La;
     };
     L.asm_big = make((int)big.size(), [&](int t) { return asm_chunks(cols(t) / 3); });
+    L.asm_tile = make((int)big.size(), [&](int t) { return at_tiles(cols(t) / 3); });
     {   // back substitution of the multi-workgroup fronts 128 columns at a time (k_backsolve_blk): fronts whose inverse
         // diagonal blocks are kept (keep_inv) and whose update-row product comes from k_backsolve_gemv (or is empty);
         // the whole level or nothing: chains + helpers must fit BSB_MAX_WGS workgroups
@@ -894,6 +896,7 @@ static void set_small_attr() {
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_block_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_assemble_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_block_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_block_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
@@ -1069,8 +1072,12 @@ static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, 
     }
     if (L.n_big) {
         tic(K_ASSEMBLE_BIG);
-        hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, tab + L.asm_big.list_off,
-                           tab + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
+        if (g_opt.tile_assembly)
+            hipLaunchKernelGGL(k_assemble_tile, dim3(L.asm_tile.grid), dim3(TPB), at_lds(), s, c.dp, tab + L.asm_tile.list_off,
+                               tab + L.asm_tile.pre_off, L.asm_tile.n, c.d_pool.p, c.d_H.p);
+        else
+            hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, tab + L.asm_big.list_off,
+                               tab + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
         toc();
         enqueue_big_steps(c, L, s, tic, toc, la, tab);
     }
@@ -1489,7 +1496,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         if (lev_dirty[l].empty()) continue;
         LevelPlan &L = dl[l];
         const int sh = (int)I.tab_used;
-        L.all_off += sh; L.small_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
+        L.all_off += sh; L.small_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh; L.asm_tile.list_off += sh; L.asm_tile.pre_off += sh;
         for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
@@ -1609,8 +1616,12 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         const LevelPlan &L = dl[l];
         if (L.n_small) launch_front_small(c, L, s);
         if (L.n_big) {
-            hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
-                               c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
+            if (g_opt.tile_assembly)
+                hipLaunchKernelGGL(k_assemble_tile, dim3(L.asm_tile.grid), dim3(TPB), at_lds(), s, c.dp, c.d_tab.p + L.asm_tile.list_off,
+                                   c.d_tab.p + L.asm_tile.pre_off, L.asm_tile.n, c.d_pool.p, c.d_H.p);
+            else
+                hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
+                                   c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
             enqueue_big_steps(c, L, s, [](int) {}, []() {});
         }
     }
@@ -2912,6 +2923,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "left_panels") g_opt.left_panels = (int)v;
     else if (k == "block_panels") g_opt.block_panels = (int)v;
     else if (k == "blk_backsolve") g_opt.blk_backsolve = (int)v;
+    else if (k == "tile_assembly") g_opt.tile_assembly = (int)v;
     else if (k == "batch_extend") g_opt.batch_extend = (int)v;
     else if (k == "extend_tail_fronts") g_opt.extend_tail_fronts = (int)v;
     else if (k == "mem_cap_mb") g_opt.mem_cap_mb = (int)v;
