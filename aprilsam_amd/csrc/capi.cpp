@@ -143,7 +143,8 @@ long long aprilsam_amd_shard_plan(const aprilsam_amd_plan_t *plan, int world, in
     if (!plan || world < 1) return -1;
     std::vector<int> owner; std::vector<char> top; std::vector<long long> xfer, bcast, v;
     asam::shard_map(plan->P, world, owner, top, xfer, bcast);
-    if (what == 1) v = xfer; else if (what == 2) v = bcast; else if (what == 3) v.assign(owner.begin(), owner.end()); else return -1;
+    if (what == 1) v = xfer; else if (what == 2) v = bcast; else if (what == 3) v.assign(owner.begin(), owner.end());
+    else if (what == 4) v = asam::shard_critical_path(plan->P, world, owner, top); else return -1;
     if (out) for (long long i = 0; i < (long long)v.size() && i < cap; i++) out[i] = v[i];
     return (long long)v.size();
 }

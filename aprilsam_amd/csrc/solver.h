@@ -67,6 +67,7 @@ int api_device_count();
 int selftest();
 struct Plan;
 void shard_map(const Plan &P, int world, std::vector<int> &owner, std::vector<char> &top, std::vector<long long> &xfer, std::vector<long long> &bcast);
+std::vector<long long> shard_critical_path(const Plan &P, int world, const std::vector<int> &owner, const std::vector<char> &top);
 int api_set_device(int d);
 int api_set_option(const char *name, double v);
 

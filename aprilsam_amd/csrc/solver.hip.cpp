@@ -2486,6 +2486,24 @@ void shard_map(const Plan &P, int world, std::vector<int> &owner, std::vector<ch
     }
 }
 
+// modelled critical path of a mapping, in sum c_j^2 flops.  Fronts whose rank range spans more than one rank ("top" fronts) each
+// run on ONE owner; those on different branches run side by side, those on one root path one after the other: the serial
+// part is the heaviest root path through the top fronts.  Below them every rank works through its own subtrees in parallel.
+// {whole factorisation, heaviest root path of top fronts, busiest rank's subtrees, all top fronts together}
+std::vector<long long> shard_critical_path(const Plan &P, int world, const std::vector<int> &owner, const std::vector<char> &top) {
+    double total = 0, topall = 0, path_max = 0; std::vector<double> local(world, 0.0), path(P.nF, 0.0);
+    for (int t = 0; t < P.nF; t++) {                    // (fronts are numbered children before parents)
+        const double ns = 3.0 * P.f_nsb[t], nu = 3.0 * P.f_nub[t];
+        double fl = 0; for (int q = 0; q < (int)ns; q++) { const double cj = (ns - q) + nu + 1; fl += cj * cj; }
+        total += fl;
+        if (!top[t]) { local[owner[t]] += fl; continue; }
+        topall += fl; path[t] += fl;
+        path_max = std::max(path_max, path[t]);
+        if (P.f_parent[t] >= 0) path[P.f_parent[t]] = std::max(path[P.f_parent[t]], path[t]);
+    }
+    return { (long long)total, (long long)path_max, (long long)*std::max_element(local.begin(), local.end()), (long long)topall };
+}
+
 // Every rank calls this with the same graph.  Builds the (identical) plan, the ownership map, THIS rank's pool layout
 // (owned fronts + ghosts), launch tables and exchange buffers.  A transport must be attached before the first
 // iteration unless world == 1 (shard_comm_init_rccl / shard_comm_init_host).
@@ -2579,19 +2597,7 @@ long long shard_info(const april_graph_cholesky_param_t *param, int what, long l
     else if (what == 1) v = S.xfer;
     else if (what == 2) v = S.bcast;
     else if (what == 3) v.assign(S.owner.begin(), S.owner.end());
-    else if (what == 4) {
-        // modelled critical path of this mapping, in sum c_j^2 flops: the fronts whose rank range spans more than one rank run one
-        // after the other on their owners (serial part); below them every rank works through its own subtrees in parallel
-        const Plan &P = ic->second->plan;
-        double total = 0, top = 0; std::vector<double> local(S.world, 0.0);
-        for (int t = 0; t < P.nF; t++) {
-            const double ns = 3.0 * P.f_nsb[t], nu = 3.0 * P.f_nub[t];
-            double fl = 0; for (int q = 0; q < (int)ns; q++) { const double cj = (ns - q) + nu + 1; fl += cj * cj; }
-            total += fl;
-            if (S.top[t]) top += fl; else local[S.owner[t]] += fl;
-        }
-        v = { (long long)total, (long long)top, (long long)*std::max_element(local.begin(), local.end()) };
-    }
+    else if (what == 4) v = shard_critical_path(ic->second->plan, S.world, S.owner, S.top);
     if (out) for (long long i = 0; i < (long long)v.size() && i < cap; i++) out[i] = v[i];
     return (long long)v.size();
 }

@@ -137,8 +137,9 @@ class ShardedSolver:
     def modelled_speedup(self):
         """bound on the speed-up of the factorisation under this mapping: fronts that span several ranks are serial (one owner each),
         below them every rank works through its own subtrees (aprilsam_amd_shard_info what = 4)"""
-        total, top, local = (float(v) for v in self._info(4))
-        return {"flops_total": total, "flops_serial_top_fronts": top, "flops_busiest_rank_subtrees": local, "speedup_bound": total / max(top + local, 1.0)}
+        total, path, local, topall = (float(v) for v in self._info(4))
+        return {"flops_total": total, "flops_heaviest_root_path_of_top_fronts": path, "flops_busiest_rank_subtrees": local,
+                "flops_all_top_fronts": topall, "speedup_bound": total / max(path + local, 1.0)}
 
     def comm_bytes_per_iteration(self):
         return int(8 * (self.xfer[:, 5].sum() + 3 * self.bcast[:, 4].sum() * (self.world - 1)))

@@ -337,8 +337,9 @@ int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, doubl
  *   shard_info what: 0 -> {levels, fronts, nodes, pool doubles of this rank, pool doubles of the whole plan};
  *                    1 -> transfers {level, front, src, dst, (unused), packed count in doubles};
  *                    2 -> broadcasts {level, front, owner, first position, blocks}; 3 -> owner rank per front;
- *                    4 -> modelled critical path in sum c_j^2 flops {whole factorisation, fronts spanning several ranks (run one
- *                         after the other), the busiest rank's own subtrees}: speed-up bound = [0] / ([1] + [2])
+ *                    4 -> modelled critical path in sum c_j^2 flops {whole factorisation, heaviest root path through the fronts that
+ *                         span several ranks (each runs on one owner), the busiest rank's own subtrees, all such fronts together}:
+ *                         speed-up bound = [0] / ([1] + [2])
  * Return codes: 0 ok; -1 bad arguments / no shard_begin; -2 non-positive pivot; -4 foreign factor types; -5 librccl.so not
  * loadable; -6 communication error (RCCL or host callback; message on stderr); -7 no transport attached. */
 typedef struct aprilsam_amd_host_comm {
@@ -372,7 +373,7 @@ void aprilsam_amd_plan_destroy(aprilsam_amd_plan_t *plan);
  *       "factor_front", "stats" (n_fronts, n_levels, max_rows, nnzL, flops) */
 long long aprilsam_amd_plan_query(const aprilsam_amd_plan_t *plan, const char *what, long long **out);
 /* Ownership map and exchange lists of a `world`-rank sharded run of this plan, as aprilsam_amd_shard_info reports them
- * (what: 1 transfers x6, 2 broadcasts x5, 3 owner per front); host logic only. */
+ * (what: 1 transfers x6, 2 broadcasts x5, 3 owner per front, 4 modelled critical path x4); host logic only. */
 long long aprilsam_amd_shard_plan(const aprilsam_amd_plan_t *plan, int world, int what, long long *out, long long cap);
 void aprilsam_amd_free(void *p);
 
