@@ -273,6 +273,11 @@ void aprilsam_amd_clear_error(void);
  *   "block_panels"      1 (default): multi-workgroup fronts run the four panel steps of a 128-column outer block as two launches --
  *                       the 128 x 128 diagonal block factored in LDS by one workgroup, the rows below solved against it on the
  *                       matrix cores (explicit inverses of its 32 x 32 diagonal blocks); 0 = one launch per 32-column panel
+ *   "blk_backsolve"     1 (default, needs block_panels): multi-workgroup fronts are back-substituted 128 columns at a time by a chain
+ *                       workgroup + helper workgroups, with the inverse diagonal blocks the factorisation left behind; 0 = one
+ *                       workgroup per front, 32 columns at a time
+ *   "tile_assembly"     1 = big fronts assembled window by window in LDS and stored once; default 0 (chunks of block columns, zero
+ *                       fill + L2 atomics: measured faster although it moves 2.5 x the bytes)
  *   "left_panels"       (block_panels = 0) 1 (default): inside a 128-column outer block of a multi-workgroup front every panel step applies the
  *                       earlier panels' updates to its own 32 columns itself (MFMA, overlapped with the pivot chain) instead
  *                       of a "narrow" update launch after every panel; 0 = right-looking narrow updates
