@@ -25,6 +25,7 @@ struct Options {
     int persist = 1;              // batch path: the top levels of the tree (few small fronts each) as ONE launch per sweep, fronts synchronised by dependency flags
     int persist_max_fronts = 240; // ... as many top levels as fit this many fronts
     int block_panels = 1;         // big fronts: the four panel steps of a 128-column outer block as two launches (diagonal block in LDS, row solves on the matrix cores)
+    int tail_poses = 24;          // incremental path: own poses per tail front (>= 8)
     int tile_assembly = 0;        // 1: big fronts assembled window by window in LDS and stored once (measured slower than the default: chunks of block columns, zero fill + L2 atomics)
     int blk_backsolve = 1;        // wide multi-workgroup fronts: back substitution 128 columns at a time by a chain workgroup + helpers (needs block_panels)
     int left_panels = 1;          // big fronts: panel steps apply the outer block's earlier panels themselves (no narrow update launches)

@@ -84,6 +84,7 @@ static void load_env_options() {
         v = g_opt.block_panels; envd("APRILSAM_AMD_BLOCK_PANELS", &v); g_opt.block_panels = (int)v;
         v = g_opt.blk_backsolve; envd("APRILSAM_AMD_BLK_BACKSOLVE", &v); g_opt.blk_backsolve = (int)v;
         v = g_opt.tile_assembly; envd("APRILSAM_AMD_TILE_ASSEMBLY", &v); g_opt.tile_assembly = (int)v;
+        v = g_opt.tail_poses; envd("APRILSAM_AMD_TAIL_POSES", &v); g_opt.tail_poses = std::max(8, (int)v);
         v = g_opt.batch_extend; envd("APRILSAM_AMD_BATCH_EXTEND", &v); g_opt.batch_extend = (int)v;
         v = g_opt.extend_tail_fronts; envd("APRILSAM_AMD_EXTEND_TAIL_FRONTS", &v); g_opt.extend_tail_fronts = (int)v;
         v = g_opt.mem_cap_mb; envd("APRILSAM_AMD_MEM_CAP_MB", &v); g_opt.mem_cap_mb = (int)v;
@@ -603,8 +604,8 @@ template <class Fn> static int guarded_rc(const april_graph_cholesky_param_t *pa
 
 // slack reserved at plan upload so that the incremental path can append without reallocating device buffers
 constexpr int INC_NODES = 4096, INC_FACT = 16384, INC_I32 = 4 << 20, INC_DEST = 1 << 20, INC_CHILD = 1 << 18, INC_TAB = 1 << 20;
-constexpr int TAIL_POSES = 24;               // own poses per tail front of the incremental path (inc_fast_step)
-constexpr int MAX_TAIL_FRONTS = INC_NODES / TAIL_POSES + 8;
+#define TAIL_POSES (g_opt.tail_poses)         // own poses per tail front of the incremental path (inc_fast_step), option tail_poses (>= 8)
+constexpr int MAX_TAIL_FRONTS = INC_NODES / 8 + 8;
 constexpr long long INC_POOL_MIN = 8ll << 20;             // doubles (64 MB; the M3500 demo appends ~25 MB of regenerated fronts between two batch steps)
 
 // waves of a k_front_small workgroup (option small_threads)
@@ -1715,7 +1716,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         const bool grew = ext && (N > c.patN || F > patF);
         if (grew) { c.want_inc = true; c.same_topo_batches = 0; }        // (plans made from now on reserve the append slack)
         else if (ext && !c.inc.t_first.empty()) c.same_topo_batches++;
-        const int tails_after = (N - c.inc.Nb + TAIL_POSES - 1) / TAIL_POSES;
+        const int tails_after = (N - c.inc.Nb + 23) / 24;               // (extend_tail_fronts counts tail fronts of 24 poses, whatever tail_poses is)
         if (ext && N > c.inc.Nb && c.inc.cap_nodes > 0 && tails_after <= g_opt.extend_tail_fronts && (grew || (!c.inc.t_first.empty() && c.same_topo_batches <= 1))) {
             // z / W of already-packed factors edited in place by the caller (pack_factors recorded the range) only reach the
             // device through upload_factors: the patch list of inc_fast_step carries the NEW factors alone
@@ -2313,13 +2314,15 @@ static int debug_stage_impl(april_graph_t *g, april_graph_cholesky_param_t *para
 
 // debug: copy the per-front clock stamps (8 per front) written when APRILSAM_AMD_KPROF is set
 int debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    auto it = g_ctx.find(param);
-    if (it == g_ctx.end() || !it->second->d_prof.p) return -1;
-    HIPCHECK(hipDeviceSynchronize());
-    int n = std::min(n_fronts, it->second->plan.nF);
-    HIPCHECK(hipMemcpy(out, it->second->d_prof.p, (size_t)8 * PROF_SLOTS * n, hipMemcpyDeviceToHost));
-    return n;
+    return guarded_rc(param, nullptr, [&]() -> int {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_ctx.find(param);
+        if (it == g_ctx.end() || !it->second->d_prof.p) return -1;
+        HIPCHECK(hipDeviceSynchronize());
+        int n = std::min(n_fronts, it->second->plan.nF);
+        HIPCHECK(hipMemcpy(out, it->second->d_prof.p, (size_t)8 * PROF_SLOTS * n, hipMemcpyDeviceToHost));
+        return n;
+    });
 }
 // ------------------------------------------------------------------------------------------------------
 // multi-GPU: nested-dissection subtree sharding (BASELINE.json config 5)
@@ -2930,6 +2933,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "block_panels") g_opt.block_panels = (int)v;
     else if (k == "blk_backsolve") g_opt.blk_backsolve = (int)v;
     else if (k == "tile_assembly") g_opt.tile_assembly = (int)v;
+    else if (k == "tail_poses") g_opt.tail_poses = std::max(8, (int)v);
     else if (k == "batch_extend") g_opt.batch_extend = (int)v;
     else if (k == "extend_tail_fronts") g_opt.extend_tail_fronts = (int)v;
     else if (k == "mem_cap_mb") g_opt.mem_cap_mb = (int)v;
