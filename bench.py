@@ -91,7 +91,7 @@ def pmc_traffic(pmc, kernel):
 
 
 # rocprofv3 kernel names of the K_BACKSOLVE / K_PANEL_BIG slots (several kernels share a slot)
-PMC_NAMES = {"k_backsolve": ("k_backsolve_blk", "k_backsolve_t", "k_backsolve_w", "k_backsolve_gemv"), "k_panel_big": ("k_block_chain", "k_block_solve", "k_diagpanel_ll")}
+PMC_NAMES = {"k_linearize": ("k_linearize_t",), "k_backsolve": ("k_backsolve_blk", "k_backsolve_t", "k_backsolve_w", "k_backsolve_gemv"), "k_panel_big": ("k_block_chain", "k_block_solve", "k_diagpanel_ll")}
 
 
 def hbm_rooflines(prof, iters, pmc_file=None, survey_bytes=None):
@@ -115,6 +115,13 @@ def hbm_rooflines(prof, iters, pmc_file=None, survey_bytes=None):
         tr = [(pmc_traffic(pmc, n), pmc["counters"]["FETCH_SIZE"].get(n, {}).get("dispatches", 0)) for n in PMC_NAMES.get(name, (name,))] if pmc else []
         tr = [(t, d) for t, d in tr if t]
         e["traffic"] = sum(t * d for t, d in tr) / max(1, sum(d for _, d in tr)) if tr else None      # bytes per launch, averaged over the slot's kernels
+        # ... and per Gauss-Newton iteration of the profiled run (k_linearize runs once per iteration), next to the algorithmic bytes per step
+        try:
+            n_it = pmc["counters"]["FETCH_SIZE"]["k_linearize_t"]["dispatches"]
+            e["traffic_per_step"] = sum(t * d for t, d in tr) / n_it if tr else None
+            e["traffic_over_algorithmic"] = e["traffic_per_step"] / k["bytes"] if tr else None
+        except Exception:
+            pass
         e["traffic_source"] = src
         out.append(e)
     return out

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """debug: phase stamps of k_block_chain for the root front of a lattice (APRILSAM_AMD_KPROF=3):
-per panel p = 0..2: chain start, chain end, after barrier 1 (inverse in LDS), after barrier 2 (rows solved), after barrier 3 (next block ready)"""
+per panel p = 0..2, all taken by the CHAIN wave: chain start, chain end, past barrier 1 (inverse in LDS) and its own write-backs issued, past barrier 2
+(the six row blocks solved against the panel), past barrier 3 (next diagonal block updated and handed over)"""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,4 +24,4 @@ for t in (nF - 1, nF - 2):
     print(f"front {t}: (us from kernel start, last outer block it ran)")
     for q in range(3):
         v = [(b[k + 5 * q] - b[0]) * 0.01 for k in range(1, 6)]
-        print(f"  panel {q}: chain start {v[0]:6.2f}  chain end {v[1]:6.2f} (+{v[1]-v[0]:.2f})  inverse visible {v[2]:6.2f} (+{v[2]-v[1]:.2f})  rows solved {v[3]:6.2f} (+{v[3]-v[2]:.2f})  next block ready {v[4]:6.2f} (+{v[4]-v[3]:.2f})")
+        print(f"  panel {q}: chain start {v[0]:6.2f}  chain end {v[1]:6.2f} (+{v[1]-v[0]:.2f})  barrier 1 + write-backs issued {v[2]:6.2f} (+{v[2]-v[1]:.2f})  barrier 2, rows solved {v[3]:6.2f} (+{v[3]-v[2]:.2f})  barrier 3, next block ready {v[4]:6.2f} (+{v[4]-v[3]:.2f})")
