@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <tuple>
+#include <chrono>
 
 namespace asam {
 
@@ -22,6 +23,12 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
     P = Plan();
     P.N = N; P.F = F; P.leaf_nodes = leaf_nodes;
     if (N <= 0) return;
+    // APRILSAM_AMD_PLAN_PROFILE: wall-clock split of the planner phases on stderr
+    const bool prof = getenv("APRILSAM_AMD_PLAN_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tph[8]; int nph = 0;
+    auto stamp = [&] { if (prof && nph < 8) tph[nph++] = now(); };
+    stamp();
 
     // ---- pose adjacency (deduplicated CSR) ------------------------------------------------------------
     std::vector<int> ap(N + 1, 0), ai;
@@ -43,6 +50,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
         ai.resize(w); ap.swap(np);
     }
 
+    stamp();
     // ---- nested dissection tree, post-order numbering ----------------------------------------------
     NDTree tree;
     // Option pin_last = k ("recent poses last", the counterpart of the reference's constrained min-degree order,
@@ -88,6 +96,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
     std::vector<int> pos_front(N);
     for (int t = 0; t < nT; t++) for (int k = 0; k < P.f_nsb[t]; k++) pos_front[P.f_first[t] + k] = t;
 
+    stamp();
     // ---- structure of every front (block positions > own range), assembly tree -----------------------
     P.f_nub.assign(nT, 0); P.f_parent.assign(nT, -1); P.f_rows_ptr.assign(nT + 1, 0);
     std::vector<std::vector<int>> kids(nT);
@@ -130,6 +139,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
     P.ch_idx.resize(P.ch_ptr[nT]);
     for (int t = 0; t < nT; t++) std::copy(kids[t].begin(), kids[t].end(), P.ch_idx.begin() + P.ch_ptr[t]);
 
+    stamp();
     // ---- levels ------------------------------------------------------------------------------------------
     P.f_level.assign(nT, 0);
     for (int t = 0; t < nT; t++) { int par = P.f_parent[t]; if (par >= 0) P.f_level[par] = std::max(P.f_level[par], P.f_level[t] + 1); }
@@ -141,6 +151,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
     P.lev_fronts.resize(nT);
     { std::vector<int> fill(P.lev_ptr.begin(), P.lev_ptr.end() - 1); for (int t = 0; t < nT; t++) P.lev_fronts[fill[P.f_level[t]]++] = t; }
 
+    stamp();
     // ---- factor -> front assignment + deterministic gather lists -------------------------------------
     P.fac_front.assign(F, -1); P.fac_la.assign(F, -1); P.fac_lb.assign(F, -1); P.fac_swap.assign(F, 0);
     struct Dest { int front, col, row, src; };
@@ -196,6 +207,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
     compress(bd, P.bd_front_ptr, P.bd_row, P.bd_col, P.bd_src_ptr, P.bd_src);
     compress(rd, P.rd_front_ptr, dummy_row, P.rd_col, P.rd_src_ptr, P.rd_src);
 
+    stamp();
     // ---- unified destination records + contribution slots (device layout) --------------------------------
     {
         struct U { int front, col, row, src, rhs; };
@@ -226,6 +238,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
         P.n_slots = (int)all.size();
     }
 
+    stamp();
     // ---- HBM pool offsets + statistics -----------------------------------------------------------------
     P.f_off.assign(nT, 0);
     int64_t off = 0;
@@ -240,6 +253,10 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
         for (int q = 0; q < ns; q++) { double c = (double)(ns - q) + nu; P.flops += c * c; }
     }
     P.pool_doubles = off;
+    stamp();
+    if (prof && nph == 8)
+        fprintf(stderr, "aprilsam_amd planner N=%d F=%d: adjacency %.3f dissection %.3f front structure %.3f levels %.3f factor lists %.3f records+slots %.3f offsets %.3f | total %.3f ms\n",
+                N, F, tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3], tph[5] - tph[4], tph[6] - tph[5], tph[7] - tph[6], tph[7] - tph[0]);
 }
 
 }  // namespace asam
