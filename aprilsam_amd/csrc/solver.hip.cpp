@@ -1820,10 +1820,21 @@ void batch_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
 // APRILSAM_AMD_INC_PROFILE=1: host wall-clock split of the incremental steps, printed at process exit
 struct IncProf {
     bool on = false; double acc[8] = { 0 }; long long n = 0;
+    std::vector<std::array<float, 7>> steps;          // per step: the six phases + total (medians at exit)
     IncProf() { const char *e = getenv("APRILSAM_AMD_INC_PROFILE"); on = e && *e == '1'; }
     ~IncProf() {
-        if (on && n) fprintf(stderr, "aprilsam_amd inc profile over %lld steps (ms/step): pack %.4f model %.4f upload %.4f plan+enqueue %.4f d2h+sync %.4f writeback %.4f | total %.4f\n",
-                             n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5]) / n);
+        if (!on || !n) return;
+        fprintf(stderr, "aprilsam_amd inc profile over %lld steps (ms/step): pack %.4f model %.4f upload %.4f plan+enqueue %.4f d2h+sync %.4f writeback %.4f | total %.4f\n",
+                n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5]) / n);
+        double med[7];
+        for (int k = 0; k < 7; k++) {
+            std::vector<float> v(steps.size());
+            for (size_t i = 0; i < steps.size(); i++) v[i] = steps[i][k];
+            std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+            med[k] = v[v.size() / 2];
+        }
+        fprintf(stderr, "aprilsam_amd inc profile, MEDIANS (ms): pack %.4f model %.4f upload %.4f plan+enqueue %.4f d2h+sync %.4f writeback %.4f | total %.4f\n",
+                med[0], med[1], med[2], med[3], med[4], med[5], med[6]);
     }
 };
 static IncProf g_incprof;
@@ -1916,7 +1927,9 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
                tp1 - t0, tp2 - tp1, tp4 - tp3, tp5 - tp4, step_ms), fflush(stdout);
     if (g_incprof.on) {
         g_incprof.acc[0] += tp1 - t0; g_incprof.acc[1] += tp2 - tp1; g_incprof.acc[2] += tp3 - tp2; g_incprof.acc[3] += tp4 - tp3;
-        g_incprof.acc[4] += tp5 - tp4; g_incprof.acc[5] += now_ms() - tp5; g_incprof.n++;
+        const double te = now_ms();
+        g_incprof.acc[4] += tp5 - tp4; g_incprof.acc[5] += te - tp5; g_incprof.n++;
+        g_incprof.steps.push_back({ (float)(tp1 - t0), (float)(tp2 - tp1), (float)(tp3 - tp2), (float)(tp4 - tp3), (float)(tp5 - tp4), (float)(te - tp5), (float)(te - t0) });
     }
     // aprilsam.c:557-559, the wall-clock rule: "this step took longer than a third of a batch step -> start over".  The
     // reference sets start_over = INT_MAX BEFORE its solver call, whose walk then adds one per pose that newly crossed the
