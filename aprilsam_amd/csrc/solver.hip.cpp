@@ -199,7 +199,12 @@ struct GraphPack {
     std::vector<int> host_idx; HBuf<double> h_hostH; DBuf<double> d_hostH; DBuf<int> d_host_idx; int host_evaluated = 0;
     hipStream_t stream = nullptr;
     HBuf<double> h_scalar;
+    // incremental steps: the pinned mirrors h_state / h_lp and the device arrays d_state / d_lp hold the same values (mirror_sync),
+    // so a step only has to patch the poses whose host objects differ from the mirror (pack_states_diff); the step's new
+    // states go to h_out (pinned), not into the mirror
+    HBuf<double> h_out; bool mirror_sync = false; std::vector<int> changed; const double *new_states = nullptr;
     void release() {
+        h_out.release(); mirror_sync = false;
         h_fa.release(); h_fb.release(); h_z.release(); h_W.release(); h_state.release(); h_lp.release(); h_dx.release();
         d_fa.release(); d_fb.release(); d_z.release(); d_W.release(); d_state.release(); d_lp.release(); d_dx.release();
         d_chi2f.release(); d_scalar.release(); h_scalar.release(); h_hostH.release(); d_hostH.release(); d_host_idx.release(); d_upt.release();
@@ -373,6 +378,7 @@ static void upload_host_index(GraphPack &gp) {
 static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp, bool upload = true) {
     const int N = zsize(g->nodes);
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
+    if ((size_t)3 * N > gp.h_state.cap || (size_t)3 * N > gp.h_lp.cap || (size_t)3 * N > gp.d_state.cap || (size_t)3 * N > gp.d_lp.cap) gp.mirror_sync = false;   // (a buffer is about to move)
     gp.h_state.need((size_t)3 * N); gp.h_lp.need((size_t)3 * N); gp.h_dx.need((size_t)3 * N);
     for (int i = 0; i < N; i++) {
         if (i + 8 < N) __builtin_prefetch(ns[i + 8]->state);
@@ -386,6 +392,33 @@ static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp, boo
     if (!upload) return;          // (the batch step reads the pinned mirror from its first kernel, k_load_states)
     HIPCHECK(hipMemcpyAsync(gp.d_state.p, gp.h_state.p, (size_t)24 * N, hipMemcpyHostToDevice, gp.stream));
     if (with_lp) HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.h_lp.p, (size_t)24 * N, hipMemcpyHostToDevice, gp.stream));
+}
+
+// Incremental steps: compare every node's state / l_point with the pinned mirrors, copy what differs and list those poses
+// (gp.changed) -- typically the new pose, the poses the previous step updated, whatever the caller moved.  Returns true when
+// patching the listed poses brings the device arrays up to date; false when a full load is needed (mirrors and device not
+// known to agree, a buffer had to grow, or too many poses changed for patches to pay).
+static bool pack_states_diff(GraphPack &gp, const april_graph_t *g) {
+    const int N = zsize(g->nodes);
+    april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
+    bool full = !gp.mirror_sync || (size_t)3 * N > gp.d_state.cap || (size_t)3 * N > gp.d_lp.cap || (size_t)3 * N > gp.d_dx.cap;
+    gp.h_state.need((size_t)3 * N, true); gp.h_lp.need((size_t)3 * N, true); gp.h_dx.need((size_t)3 * N); gp.h_out.need((size_t)3 * N);
+    gp.d_state.need((size_t)3 * N); gp.d_lp.need((size_t)3 * N); gp.d_dx.need((size_t)3 * N);
+    gp.changed.clear();
+    const int Nold = full ? 0 : gp.N;
+    for (int i = 0; i < N; i++) {
+        if (i + 8 < N) __builtin_prefetch(ns[i + 8]->state);
+        const april_graph_node_t *n = ns[i];
+        if (n->type != APRIL_GRAPH_NODE_XYT_TYPE || n->length != 3) fail(ERR_UNSUPPORTED, "node %d: only xyt nodes (type 100, 3 DoF) are supported (aprilsam.h:94)", i);
+        double *ms = gp.h_state.p + (size_t)3 * i, *ml = gp.h_lp.p + (size_t)3 * i;
+        if (i >= Nold || memcmp(ms, n->state, 24) != 0 || memcmp(ml, n->l_point, 24) != 0) {
+            memcpy(ms, n->state, 24); memcpy(ml, n->l_point, 24);
+            gp.changed.push_back(i);
+        }
+    }
+    gp.N = N;
+    if (gp.changed.size() > 48) full = true;
+    return !full;
 }
 
 // evaluation points of the unary factors [from, to): the node's state as packed by this call (april_graph_xytpos.c:83-85
@@ -1275,7 +1308,8 @@ static void inc_prepare(Context &c) {        // after a full (re)plan: c.plan is
 // plan was made): every node re-linearised, every factor linearised, the Tikhonov term batch_lambda on every pose,
 // every front -- base and tail -- re-factorised, full back substitution.  Saves the nested dissection + symbolic analysis
 // + plan upload (6-7 ms on M3500) that a cold call pays, at the price of a less bushy tree for the appended poses.
-static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int Nold, const std::vector<RefModel::Visit> *needed, double batch_lambda = -1.0) {
+static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int Nold, const std::vector<RefModel::Visit> *needed, double batch_lambda = -1.0,
+                          bool patch_states = false) {
     IncState &I = c.inc; Plan &P = c.plan;
     const bool batch = batch_lambda >= 0;
     if (!I.ready || N < I.Nb || Fold < I.Fb) return false;
@@ -1595,14 +1629,20 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
                            gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, (const double *)nullptr,
                            nFr, c.d_flevel.p, 1, mp ? c.d_flags.p : (int *)nullptr);
     } else {
-        // states first (the new factors are linearised at them; new priors at the node's current state), then ONE single-workgroup
-        // launch for all table patches + the linearisation of the new factors
-        hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
-        if (!PL.hdr.empty() || F > Fold) {
-            const Patch *hdr = PL.finish();
-            hipLaunchKernelGGL(k_inc_prologue, dim3(1), dim3(1024), 0, s, hdr, (const char *)PL.buf.p, (int)PL.hdr.size(), Fold, F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                               gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p);
+        // states first (the new factors are linearised at them; new priors at the node's current state) -- as patches of the few
+        // poses whose host objects differ from the pinned mirror (pack_states_diff), or, when that is not known to be enough,
+        // all of them from the mirrors -- then ONE single-workgroup launch for all patches + the linearisation of the new factors
+        if (patch_states) {
+            for (int i : gp.changed) {
+                PL.add(gp.d_state.p + (size_t)3 * i, gp.h_state.p + (size_t)3 * i, 24);
+                PL.add(gp.d_lp.p + (size_t)3 * i, gp.h_lp.p + (size_t)3 * i, 24);
+            }
+        } else {
+            hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
         }
+        const Patch *hdr = PL.finish();
+        hipLaunchKernelGGL(k_inc_prologue, dim3(1), dim3(1024), 0, s, hdr, (const char *)PL.buf.p, (int)PL.hdr.size(), Fold, F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
+                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p);
     }
     for (int l = 0; l < nLev; l++) {
         if (lev_dirty[l].empty()) continue;
@@ -1631,7 +1671,10 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     // incremental steps: the state update (state = l_point + dx, pinned mirrors of state / dx / failure record) rides on the
     // back substitution of the front that owns the pose -- every visited pose lives in a front of this sweep -- instead of
     // a launch of its own over all poses
-    const UpdArgs upd = batch ? UpdArgs{} : UpdArgs{ c.d_perm.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p, gp.h_state.p, gp.h_dx.p, c.h_bad.p };
+    // (the device states are NOT touched: d_state / d_lp keep mirroring the host objects, the new states go to a pinned buffer
+    // of their own -- see pack_states_diff)
+    gp.h_out.need((size_t)3 * N);
+    const UpdArgs upd = batch ? UpdArgs{} : UpdArgs{ c.d_perm.p, gp.d_lp.p, nullptr, gp.d_dx.p, gp.h_out.p, gp.h_dx.p, c.h_bad.p };
     bool rode = false;
     for (int l = nLev - 1; l >= 0; l--) {
         if (mp && l >= 1) continue;
@@ -1651,9 +1694,14 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             rode = true;
         }
     }
-    if (batch || !rode)
+    if (batch || !rode) {
         hipLaunchKernelGGL(k_update_states, dim3((N + TPB - 1) / TPB), dim3(TPB), 0, s, N, c.d_pos.p, c.d_x.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p,
-                           batch ? gp.h_lp.p : gp.h_state.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);          // new states / dx / pivot flag straight into the pinned mirrors
+                           batch ? gp.h_lp.p : gp.h_out.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);          // new states / dx / pivot flag straight into pinned memory
+        gp.mirror_sync = false;                       // (this kernel rewrites d_state)
+    } else {
+        gp.mirror_sync = true;                        // device arrays == mirrors == what the host objects held at this call
+    }
+    gp.new_states = gp.h_out.p;
     HIPCHECK(hipGetLastError());
     for (int t : fd_dirty) I.dirty[t] = 0;
     // the pattern folded into the device structures (a later batch call compares against it)
@@ -1691,6 +1739,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     const double t0 = now_ms();
     pack_factors(gp, g);
     pack_states(gp, g, false, false);
+    gp.mirror_sync = false;                           // (a batch step leaves new states in d_state and in the l_point mirror)
     const int N = gp.N, F = gp.F;
     c.h_bad.need(4); gp.h_dx.need((size_t)3 * N);
     if (!gp.host_idx.empty()) {       // foreign factor types: their eval() reads the host objects, which the reference
@@ -1858,7 +1907,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     c.want_inc = true; c.used_inc = true;
     const double t0 = now_ms();
     pack_factors(gp, g, false);
-    pack_states(gp, g, true, false);                 // pinned mirrors only: the fast path reads them from its first kernel
+    const bool patch_states = pack_states_diff(gp, g);      // pinned mirrors; the fast path patches / loads them from its first kernels
     const int N = gp.N, F = gp.F;
     c.h_bad.need(4);
     const double tp1 = now_ms();
@@ -1877,8 +1926,9 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     c.model.plan_visit(visits);                      // structural: which poses the reference's solve_node touches
     const bool partial = c.model.naffected <= 5;     // aprilsam.c:755: otherwise the whole tree is walked
     c.h_bad.p[0] = c.h_bad.p[1] = c.h_bad.p[2] = c.h_bad.p[3] = 0;      // (the riding state update only ever writes a SET failure record)
-    bool reused = g_opt.inc_fast && gp.host_idx.empty() && inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, partial ? &visits : nullptr);
+    bool reused = g_opt.inc_fast && gp.host_idx.empty() && inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, partial ? &visits : nullptr, -1.0, patch_states);
     if (!reused) {                // the step does not fit the frozen structure (or slack ran out): full re-plan
+        gp.mirror_sync = false; gp.new_states = gp.h_state.p;
         upload_factors(gp);
         HIPCHECK(hipMemcpyAsync(gp.d_state.p, gp.h_state.p, (size_t)24 * N, hipMemcpyHostToDevice, gp.stream));
         HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.h_lp.p, (size_t)24 * N, hipMemcpyHostToDevice, gp.stream));
@@ -2002,7 +2052,7 @@ static void apply_visits(Context &c, GraphPack &gp, april_graph_t *g, april_grap
         memcpy(nd->delta_X, dx, 24);                                      // aprilsam.c:752-754
         if (!update) continue;
         if (std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2])) continue;   // april_graph_xyt.c:304-305
-        memcpy(nd->state, gp.h_state.p + (size_t)3 * n, 24);              // l_point + dx, theta wrapped (k_update_states)
+        memcpy(nd->state, gp.new_states + (size_t)3 * n, 24);             // l_point + dx, theta wrapped (state update on the device)
     }
     if (param->delta_x) {
         free(param->delta_x);
@@ -2042,6 +2092,7 @@ void inc_solve_only(april_graph_t *g, april_graph_cholesky_param_t *param) {
                            gp.h_state.p, gp.h_dx.p, c.d_bad.p, c.h_bad.p);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipStreamSynchronize(s));
+        gp.mirror_sync = false; gp.new_states = gp.h_state.p;           // (k_update_states rewrote d_state and the state mirror)
         apply_visits(c, gp, g, param, N);
         c.st.error_code = 0; c.st.ms_total = now_ms() - t0;
         if (param->show_timing) { printf("aprilsam_amd solve: N=%d visited %zu poses%s | total %.3f ms\n", N, c.visits.size(), partial ? " (marked root paths only)" : "", c.st.ms_total); fflush(stdout); }
@@ -2111,6 +2162,7 @@ static int resident_steps_impl(april_graph_t *g, april_graph_cholesky_param_t *p
     const int N = gp.N;
     HIPCHECK(hipSetDevice(g_device));
     set_small_attr();
+    gp.mirror_sync = false;                           // (states move on the device only)
     for (int i = 0; i < n; i++) {
         HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));   // relinearise
         if (mode == 1) {
@@ -2273,6 +2325,7 @@ static int debug_stage_impl(april_graph_t *g, april_graph_cholesky_param_t *para
     const Plan &P = c.plan;
     const int N = gp.N, F = gp.F;
     hipStream_t s = gp.stream;
+    gp.mirror_sync = false;
     HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL((k_linearize_t<false>), dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
                        gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, (const double *)nullptr);
@@ -2693,6 +2746,7 @@ static int shard_iterate_impl(april_graph_t *g, april_graph_cholesky_param_t *pa
     const int N = gp.N, me = S.rank;
     auto nop = [](int) {}; auto nop0 = []() {};
     Transport *T = S.tr.get();
+    gp.mirror_sync = false;
     HIPCHECK(hipMemsetAsync(c.d_bad.p, 0, 16, s));          // sticky over the n iterations: the first failure is the one reported
     for (int iter = 0; iter < n; iter++) {
         HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));      // relinearise
