@@ -50,31 +50,60 @@ class ShardedSolver:
         self.xfer = self._info(1).reshape(-1, 6)       # level, front, src, dst, -, packed count
         self.bcast = self._info(2).reshape(-1, 5)      # level, front, owner, first position, blocks
         self.owner = self._info(3)
+        self.transport_note = None
         if world > 1 or backend == "nccl":
             if backend == "nccl":
-                self._init_rccl(device)
+                # RCCL inside the library; if the communicator cannot be created on ANY rank (librccl not loadable next to this
+                # HIP runtime, a clash with the RCCL the host framework bundles, ...) every rank falls back to the host-callback
+                # transport over a gloo group -- slower (pinned staging), but the same schedule and the same results
+                err = None
+                try:
+                    self._init_rccl(device)
+                except Exception as e:                # noqa: BLE001
+                    err = repr(e)
+                ok = self._all_ok(err is None, device)
+                if not ok:
+                    self.transport_note = f"RCCL transport unavailable ({err or 'failed on another rank'}): host callbacks over gloo instead"
+                    if world > 1:
+                        self._gloo = dist.new_group(backend="gloo")
+                        self.backend = "gloo (fallback)"
+                        self._init_host(self._gloo)
             else:
                 self._init_host()
 
+    def _all_ok(self, mine, device):
+        """logical AND of `mine` over the ranks (through the process group the launcher set up)"""
+        if self.world <= 1:
+            return mine
+        torch, dist = self.torch, self.dist
+        dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+        t = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
     # -- transports ---------------------------------------------------------------------------------------------------
     def _init_rccl(self, device):
-        """rank 0 asks the library for an RCCL unique id; torch.distributed only carries these 128 bytes"""
+        """rank 0 asks the library for an RCCL unique id; torch.distributed only carries these 128 bytes.  Before the collective
+        ncclCommInitRank every rank checks that IT can load RCCL at all (a rank that cannot would leave the others waiting
+        inside the collective): the check is the id call itself, into a scratch buffer, and its outcome is AND-ed over the ranks"""
         torch, dist = self.torch, self.dist
         buf = C.create_string_buffer(128)
-        if self.rank == 0:
-            rc = self.lib.dll.aprilsam_amd_shard_comm_unique_id(buf)
-            if rc != 0:
-                raise RuntimeError(f"shard_comm_unique_id rc={rc}")
+        rc = self.lib.dll.aprilsam_amd_shard_comm_unique_id(buf)          # (loads librccl next to the library's HIP runtime)
+        import os
+        if os.environ.get("APRILSAM_AMD_TEST_RCCL_UNAVAILABLE") == str(self.rank):      # tests: this rank pretends it cannot load RCCL
+            rc = -5
+        if not self._all_ok(rc == 0, device):
+            raise RuntimeError(f"librccl not usable on every rank (shard_comm_unique_id rc={rc} here)")
         if self.world > 1:
             dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
             t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=dev if dist.get_backend() == "nccl" else "cpu")
-            dist.broadcast(t, src=0)
+            dist.broadcast(t, src=0)                                        # rank 0's id wins
             buf = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
         rc = self.lib.dll.aprilsam_amd_shard_comm_init_rccl(self._p, buf)
         if rc != 0:
             raise RuntimeError(f"shard_comm_init_rccl rc={rc}")
 
-    def _init_host(self):
+    def _init_host(self, group=None):
         torch, dist = self.torch, self.dist
 
         def view(ptr, n):
@@ -91,10 +120,10 @@ class ShardedSolver:
             return run
 
         self._cb = HostComm(None,
-                            _SEND(guard(lambda u, p, n, dst: dist.send(view(p, n), dst=int(dst)))),
-                            _RECV(guard(lambda u, p, n, src: dist.recv(view(p, n), src=int(src)))),
-                            _BCAST(guard(lambda u, p, n, root: dist.broadcast(view(p, n), src=int(root)))),
-                            _ALLRED(guard(lambda u, p, n: dist.all_reduce(view(p, n)))))
+                            _SEND(guard(lambda u, p, n, dst: dist.send(view(p, n), dst=int(dst), group=group))),
+                            _RECV(guard(lambda u, p, n, src: dist.recv(view(p, n), src=int(src), group=group))),
+                            _BCAST(guard(lambda u, p, n, root: dist.broadcast(view(p, n), src=int(root), group=group))),
+                            _ALLRED(guard(lambda u, p, n: dist.all_reduce(view(p, n), group=group))))
         rc = self.lib.dll.aprilsam_amd_shard_comm_init_host(self._p, C.byref(self._cb))
         if rc != 0:
             raise RuntimeError(f"shard_comm_init_host rc={rc}")
@@ -130,6 +159,8 @@ class ShardedSolver:
         self.lib.dll.aprilsam_amd_shard_comm_info(self._p, out, path, 512)
         kind = {0: "none (single rank)", 1: "RCCL point-to-point on the solver stream", 2: "host callbacks over " + self.backend}[int(out[0])]
         v = int(out[3])
+        if self.transport_note:
+            kind += " -- " + self.transport_note
         return {"transport": kind, "ncclCommCount": int(out[1]), "ncclCommUserRank": int(out[2]),
                 "rccl_version": f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v else None, "librccl": path.value.decode() or None,
                 "hip_device": int(out[4])}

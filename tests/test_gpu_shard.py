@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, K, iters, out):
+def _worker(rank, world, port, K, iters, out, backend="gloo", env=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(env or {})
     sys.path.insert(0, ROOT)
     import zlib
     import torch.distributed as dist
@@ -25,7 +26,9 @@ def _worker(rank, world, port, K, iters, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = host.SolverLib()
     g = lib.new_graph(); lib.dll.aprilsam_amd_make_lattice(g.ptr, K); p = lib.new_param()
-    sol = ShardedSolver(lib, g, p, rank, world, backend="gloo")
+    sol = ShardedSolver(lib, g, p, rank, world, backend=backend)
+    if env:
+        assert sol.transport_note and "host callbacks over gloo" in sol.comm_info()["transport"], sol.comm_info()
     chi2 = [sol.chi2()]
     for _ in range(iters):
         sol.iterate(1)
@@ -41,13 +44,13 @@ def _worker(rank, world, port, K, iters, out):
     dist.barrier(); dist.destroy_process_group()
 
 
-def _run(world, K, iters, timeout=900):
+def _run(world, K, iters, timeout=900, backend="gloo", env=None):
     import torch.multiprocessing as mp
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = 29600 + os.getpid() % 2000 + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, K, iters, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, K, iters, out, backend, env)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -118,6 +121,18 @@ def test_sharded_1m_lattice_matches_the_single_gpu_trace(built, lib, world):
     want = np.array(bench.LATTICE1M_CHI2[:2])
     assert np.max(np.abs(c1 - want) / want) < 1e-9
     _check(res, st, world, want, s1)
+
+
+def test_rccl_unavailable_on_one_rank_falls_back_to_host_callbacks_everywhere(built, lib):
+    """the launcher asks for the RCCL transport, rank 1 cannot load RCCL: every rank must notice BEFORE the collective
+    communicator set-up (a rank missing from ncclCommInitRank would hang the others) and the run continues over the
+    host-callback transport on a gloo group, with the same results"""
+    K = 24
+    G = np.load(os.path.join(ROOT, "tests", "golden", f"lattice_{K}.npz"))
+    iters = len(G["chi2"]) - 1
+    res, st = _run(2, K, iters, backend="nccl", env={"APRILSAM_AMD_TEST_RCCL_UNAVAILABLE": "1"})
+    c1, s1 = _single_gpu_states(lib, K, iters)
+    _check(res, st, 2, G["chi2"], s1)
 
 
 def test_rccl_transport_on_one_rank(built, lib):
