@@ -13,6 +13,10 @@ struct Options {
     int trust_factor_cache = 0;   // 1: z/W of factors already packed are treated as immutable (skips the per-call content check)
     int small_lds_kb = 156;       // fronts whose LDS image fits run in the single-workgroup LDS kernel
     int inc_fast = 1;             // incremental steps regenerate only the dirty root paths (0: full re-plan per step)
+    int inc_multi = 1;            // incremental steps: the regenerated fronts of all levels as ONE multi-level launch, the back substitution as another (0: one launch per level)
+    int inc_one = 1;              // ... and a step that regenerates at most inc_one_up fronts and walks at most inc_one_dn as ONE single-workgroup launch
+    int inc_one_up = 3, inc_one_dn = 4, inc_one_threads = 512, inc_one_spin = 1;
+    int inc_tail = 1;             // ... and steps whose factors touch the last few poses of the last tail front alone re-factorise its trailing columns only
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
     int small_threads = 1024;     // workgroup size of k_front_small (256 / 512 / 1024) on latency-bound levels ...
     int tp_threads = 512;         // ... and on throughput levels (>= tp_fronts fronts)

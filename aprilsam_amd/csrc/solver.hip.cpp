@@ -74,6 +74,13 @@ static void load_env_options() {
         v = g_opt.tp_threads; envd("APRILSAM_AMD_TP_THREADS", &v); g_opt.tp_threads = (int)v;
         v = g_opt.lookahead; envd("APRILSAM_AMD_LOOKAHEAD", &v); g_opt.lookahead = (int)v;
         v = g_opt.inc_fast; envd("APRILSAM_AMD_INC_FAST", &v); g_opt.inc_fast = (int)v;
+        v = g_opt.inc_multi; envd("APRILSAM_AMD_INC_MULTI", &v); g_opt.inc_multi = (int)v;
+        v = g_opt.inc_one; envd("APRILSAM_AMD_INC_ONE", &v); g_opt.inc_one = (int)v;
+        v = g_opt.inc_one_up; envd("APRILSAM_AMD_INC_ONE_UP", &v); g_opt.inc_one_up = (int)v;
+        v = g_opt.inc_one_dn; envd("APRILSAM_AMD_INC_ONE_DN", &v); g_opt.inc_one_dn = (int)v;
+        v = g_opt.inc_one_threads; envd("APRILSAM_AMD_INC_ONE_THREADS", &v); g_opt.inc_one_threads = (int)v;
+        v = g_opt.inc_one_spin; envd("APRILSAM_AMD_INC_ONE_SPIN", &v); g_opt.inc_one_spin = (int)v;
+        v = g_opt.inc_tail; envd("APRILSAM_AMD_INC_TAIL", &v); g_opt.inc_tail = (int)v;
         v = g_opt.block_factor; envd("APRILSAM_AMD_BLOCK_FACTOR", &v); g_opt.block_factor = (int)v;
         v = g_opt.fused_panel; envd("APRILSAM_AMD_FUSED_PANEL", &v); g_opt.fused_panel = (int)v;
         v = g_opt.persist; envd("APRILSAM_AMD_PERSIST", &v); g_opt.persist = (int)v;
@@ -472,6 +479,9 @@ struct IncState {
     std::vector<long long> cur_cap;         // per front: doubles allocated at fd.off
     std::vector<char> dirty;
     std::vector<int> f_level;               // base levels, tail front i = nLev0 + i
+    int zpos = 0;                           // a position whose x entries stay zero: what the phantom rows of the last tail front point at
+    int tail_ok = -1;                       // tail front whose factor on the device is complete in the padded layout (candidate for tail_refactor), or -1
+    int recs_stale = -1;                    // tail front whose destination records on the device lack the factors tail_refactor took in directly, or -1
     std::vector<int> t_first, t_cnt;        // tail fronts: first pose id, own poses
     std::vector<int> tf_of;                 // tail pose (id - Nb) -> its tail front
     std::vector<std::vector<int>> kids;     // per front: children that are NOT in the base plan's child lists (children of tail fronts)
@@ -498,6 +508,7 @@ struct Context {
     DBuf<double> d_pool, d_H, d_x, d_diag;   // d_diag: factored diagonal blocks of the current panel step, one per active big front
     DBuf<int> d_bad;
     HBuf<int> h_bad;
+    HBuf<long long> h_kstamp; HBuf<int> h_done; int done_seq = 0, one_wait = 0;      // k_inc_one: phase stamps (profile), completion word the host spins on
     std::vector<double> h_lambda;
     aprilsam_amd_stats_t st{};
     hipEvent_t ev[8] = {};
@@ -645,6 +656,7 @@ constexpr long long INC_POOL_MIN = 8ll << 20;             // doubles (64 MB; the
 static int waves_of(int nt) { return nt >= 1024 ? 16 : (nt >= 512 ? 8 : 4); }
 // workgroup size of k_front_small on a level with n fronts: latency levels take the big workgroup (more lanes on one
 // front's critical path), throughput levels the smaller one (more workgroups per CU)
+static const bool g_incprof_stamps = [] { const char *e = getenv("APRILSAM_AMD_INC_PROFILE"); return e && *e == '2'; }();      // (see IncProf)
 static int small_threads_for(size_t n_fronts) { return (int)n_fronts >= g_opt.tp_fronts ? std::min(g_opt.small_threads, g_opt.tp_threads) : g_opt.small_threads; }
 
 // doubles of d_diag a level needs: one (NB x NB+1) slot per parked diagonal block (per-panel forms) or four NB x NB inverse
@@ -909,7 +921,9 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     const long long pool_doubles = lay ? lay->pool_doubles : P.pool_doubles;
     c.d_pool.need((size_t)std::max<long long>(pool_doubles, 1) + (size_t)pool_slack);
     c.inc.pool_used = pool_doubles; c.inc.pool_cap = (long long)c.d_pool.cap;
-    c.d_H.need((size_t)9 * ((size_t)std::max(1, P.n_slots) + (size_t)5 * INC_FACT_)); c.d_x.need((size_t)3 * ((size_t)P.N + INC_NODES_));
+    c.d_H.need((size_t)9 * ((size_t)std::max(1, P.n_slots) + (size_t)5 * INC_FACT_)); c.d_x.need((size_t)3 * ((size_t)P.N + INC_NODES_ + 1));
+    c.inc.zpos = P.N + INC_NODES_;
+    HIPCHECK(hipMemsetAsync(c.d_x.p + (size_t)3 * c.inc.zpos, 0, 24, s));
     c.inc.slots_used = P.n_slots;
     c.inc.ready = false; c.inc.t_first.clear(); c.same_topo_batches = 0;
     c.d_bad.need(4); c.h_bad.need(4);
@@ -1296,7 +1310,7 @@ static void inc_prepare(Context &c) {        // after a full (re)plan: c.plan is
     I.dirty.assign(P.nF, 0);
     I.f_level.assign(P.f_level.begin(), P.f_level.end());
     I.fd.resize(P.nF);
-    I.t_first.clear(); I.t_cnt.clear(); I.tf_of.clear(); I.kids.assign(P.nF, {});
+    I.t_first.clear(); I.t_cnt.clear(); I.tf_of.clear(); I.kids.assign(P.nF, {}); I.tail_ok = -1; I.recs_stale = -1;
     I.base_levels = c.levels;
     c.inc_slot_blk.clear(); c.inc_slot_rhs.clear();
     I.ready = true;
@@ -1323,6 +1337,23 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         const int *it = std::lower_bound(b, e, p);
         return (it == e || *it != p) ? -1 : P.f_nsb[t] + (int)(it - b);
     };
+    // The commonest step -- new poses and factors among the last few poses of the LAST tail front -- re-factorises that front's
+    // trailing columns only (tail_refactor, kernels.hip.h): the front's factor on the device must be complete, its array
+    // keeps its shape (phantom rows, below), and nothing else may be touched by the step's factors.
+    bool tail_fast = false; TailStep tstep{ -1, 0, 0 };
+    if (!batch && g_opt.inc_tail && g_opt.inc_multi && g_opt.persist && !I.t_first.empty() && I.tail_ok == nF0 + (int)I.t_first.size() - 1 && F > Fold) {
+        const int first = I.t_first.back(), n_old = I.t_cnt.back(), n_new = n_old + (N - std::max(Nold, Nb));
+        int lo = first + n_old;                        // (poses added by this step: all of their columns are new)
+        bool ok = n_new <= TAIL_POSES && I.E.back().empty();
+        for (int f = Fold; f < F && ok; f++) {
+            const int a = fa[f], b = fb[f];
+            ok = a >= first && (b < 0 || b >= first);
+            lo = std::min(lo, b >= 0 ? std::min(a, b) : a);
+        }
+        if (ok && n_new - (lo - first) <= TAILK) { tail_fast = true; tstep = TailStep{ nF0 + (int)I.t_first.size() - 1, lo - first, n_old }; }
+    }
+    // (any other way of factorising that front reads its destination records: they are brought up to date first)
+    if (!tail_fast && I.recs_stale >= 0) I.dirty[I.recs_stale] = 1;
     // ---- 0. new poses join the last tail front, or open the next one --------------------------------------------------
     auto n_tail = [&]() { return (int)I.t_first.size(); };
     for (int k = std::max(Nold, Nb); k < N; k++) {
@@ -1410,9 +1441,21 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         const bool tail = is_tail(t);
         const int nsb = nsb_of(t), nub0 = nub0_of(t);
         const std::vector<int> &E = I.E[t];
-        const int nub = nub0 + (int)E.size(), nbc = nsb + nub;
+        // the last tail front keeps the shape of a FULL one while it fills up: phantom structure rows (zero rows of L, x taken
+        // from a position that stays zero) stand in for the poses still to come, so that its leading dimension and the place of
+        // its right-hand-side row do not move when a pose arrives -- what tail_refactor relies on
+        const int nph = (tail && t == nFr - 1 && g_opt.inc_tail && E.empty()) ? std::max(0, TAIL_POSES - nsb) : 0;
+        const int nub = nub0 + (int)E.size() + nph, nbc = nsb + nub;
         const long long need = (long long)(3 * (nbc + 1)) * (3 * nbc);
         FrontDesc &D = I.fd[t];
+        if (tail_fast && t == tstep.t) {               // only the descriptor changes: records, children and array stay
+            D.nsb = nsb; D.nub = nub; I.cur_nub[t] = nub;
+            for (int f = Fold; f < F; f++) new_swap[f - Fold] = fb[f] >= 0 && fa[f] < fb[f];      // (own poses: local order = id order; see add_factor below)
+            fd_dirty.push_back(t);
+            I.recs_stale = t;
+            continue;
+        }
+        if (t == I.recs_stale) I.recs_stale = -1;
         if (need > I.cur_cap[t]) {
             // growing fronts (the last tail front, fronts collecting tail rows) get head-room: no new array every step
             const int gb = tail ? std::max(nbc + 4, TAIL_POSES + (int)E.size() + 4) : nbc + 4;
@@ -1427,6 +1470,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         D.rows_begin = (int)(i32_base + (long long)st_i32.size());
         if (!tail) st_i32.insert(st_i32.end(), P.f_rows.begin() + P.f_rows_ptr[t], P.f_rows.begin() + P.f_rows_ptr[t + 1]);
         st_i32.insert(st_i32.end(), E.begin(), E.end());
+        if (nph > 0) st_i32.insert(st_i32.end(), (size_t)TAIL_POSES, I.zpos);       // (phantom rows; a full run: the descriptor's nub shrinks as the front fills up)
         auto local = [&](int node) -> int {            // local block index of a node in this front
             if (node >= Nb) {
                 if (tail && node < D.first + nsb) return node - D.first;
@@ -1541,7 +1585,10 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         for (auto &x : L.btile) { x.list_off += sh; x.pre_off += sh; }
         L.bs_blk.list_off += sh; L.bs_blk.pre_off += sh; L.rest_off += sh;
         L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh; L.wb_off += sh;
-        if (l < I.nLev0) for (int t : lev_dirty[l]) I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
+        if (l < I.nLev0) for (int t : lev_dirty[l]) {
+            I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
+            I.base_levels[l].solve_w_lds = std::max(I.base_levels[l].solve_w_lds, backsolve_lds(3 * (P.f_nsb[t] + I.cur_nub[t]), 3 * P.f_nsb[t], true));
+        }
     }
     for (int l = 0; l < nLev; l++) if (diag_doubles(dl[l].n_big, dl[l].n_diag_slots) > c.d_diag.cap) return false;
     // batch on the extended plan: levels >= 1 as ONE multi-level launch per sweep (see enqueue_numeric), when they hold small
@@ -1573,6 +1620,64 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     }
     auto solve_lds_of = [&](int t) { return (size_t)(3 * (nsb_of(t) + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8; };
     for (int t = 0; t < nFr; t++) if (I.need[t] && solve_lds_of(t) > 160 * 1024) return false;
+    // incremental step: the regenerated fronts of ALL levels as one multi-level launch (dependency flags, as the batch sweeps
+    // do over the top of the tree), and the back substitution from the top as another -- a step that touches a root path is
+    // three launches (prologue, fronts, back substitution + state update) instead of one per level and direction
+    int iu_off = 0, iu_n = 0, iu_nt = 0; size_t iu_lds = 0; long long iu_full = 0;
+    int id_off = 0, id_n = 0, id_maxns = 0, id_rest = -1; size_t id_lds = 0;      // id_rest: first level (downwards) left to per-level launches
+    bool iu = !batch && g_opt.persist && g_opt.inc_multi, id = iu;
+    if (iu) {
+        const int sh = (int)I.tab_used;
+        for (int l = 0; l < nLev && iu; l++) {
+            if (lev_dirty[l].empty()) continue;
+            const LevelPlan &L = dl[l];
+            if (iu_nt == 0) iu_nt = L.small_nt;
+            iu = L.n_big == 0 && L.n_small == L.n_all && L.small_nt == iu_nt;
+            iu_n += L.n_all; iu_lds = std::max(iu_lds, L.small_lds); iu_full = std::max(iu_full, L.full_limit);
+        }
+        iu = iu && (iu_n >= 1 || tail_fast) && iu_n <= g_opt.persist_max_fronts;
+        if (iu) {
+            iu_off = sh + (int)tab.size();
+            for (int l = 0; l < nLev; l++) if (!lev_dirty[l].empty()) for (int k = 0; k < dl[l].n_small; k++) tab.push_back(tab[dl[l].small_off - sh + k]);
+        }
+    }
+    if (id) {
+        if (needed) {                                   // the lists of the marked root paths are contiguous, top level first
+            id_off = bs_off[nLev - 1];
+            for (int l = nLev - 1; l >= 0; l--) { id_n += bs_n[l]; id_lds = std::max(id_lds, bs_wlds[l]); id_maxns = std::max(id_maxns, bs_maxns[l]); }
+            id = id_n >= 1 && id_n <= g_opt.persist_max_fronts && id_lds <= 160 * 1024;
+        } else {                                        // every pose: the tail fronts and as many base levels as may be resident together
+            id_off = (int)(I.tab_used + (long long)tab.size());
+            id_rest = nLev - 1;
+            for (int l = nLev - 1; l >= 0; l--) {
+                size_t lds = 0; int mx = 0, n = 0;
+                if (l >= I.nLev0) { const int t = nF0 + (l - I.nLev0); lds = backsolve_lds(3 * (nsb_of(t) + I.cur_nub[t]), 3 * nsb_of(t), true); mx = 3 * nsb_of(t); n = 1; }
+                else { const LevelPlan &L = I.base_levels[l]; lds = L.solve_w_lds; mx = L.maxns; n = L.n_all; }
+                if (id_n + n > g_opt.persist_max_fronts || std::max(id_lds, lds) > 160 * 1024) break;
+                if (l >= I.nLev0) tab.push_back(nF0 + (l - I.nLev0));
+                else for (int k = 0; k < n; k++) tab.push_back(c.base_tab[I.base_levels[l].all_off + k]);
+                id_n += n; id_lds = std::max(id_lds, lds); id_maxns = std::max(id_maxns, mx); id_rest = l - 1;
+            }
+            id = id_n >= 2;
+            if (!id) id_rest = -1;
+        }
+    }
+    // ... and a step that regenerates a front or three and walks a short root path runs as ONE launch of one workgroup
+    // (k_inc_one: prologue, fronts, back substitution one after the other)
+    bool one = iu && id && needed && g_opt.inc_one && iu_n <= g_opt.inc_one_up && id_n <= g_opt.inc_one_dn && id_maxns <= BSW_MAX_NS && g_opt.wave_backsolve;
+    const int one_nt = g_opt.inc_one_threads >= 1024 ? 1024 : g_opt.inc_one_threads >= 512 ? 512 : 256;
+    size_t one_lds = std::max(id_lds, tail_fast ? tail_refactor_lds() : (size_t)0);
+    if (one) {
+        for (int l = 0; l < nLev; l++) for (int t : lev_dirty[l]) {         // the kernel's own full / panel decision, at its thread count
+            const int R = 3 * (nsb_of(t) + I.cur_nub[t] + 1), C = R - 3;
+            const size_t full = small_front_lds(R, C, one_nt / 64);
+            one_lds = std::max(one_lds, (long long)full <= iu_full ? full : panel_front_lds(R, 3 * nsb_of(t), one_nt / 64));
+        }
+        one = one_lds <= 160 * 1024;
+    }
+    if (!one) { iu = iu && iu_n >= 2; id = id && id_n >= 2; }
+    if (tail_fast && !one && tail_refactor_lds() > 64 * 1024) return false;       // (never: the refactorisation alone runs as k_inc_one without lists)
+    if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return false;
     c.st.reserved0 = (int)fd_dirty.size();              // fronts regenerated by this step (tools/inc_hist.py)
     // ---- 4. uploads: every table update of this step, the new factors and the new states through ONE pinned staging
     //         buffer, scattered by one kernel (k_apply_patches) -- no copy-engine call on the path ---------------------------
@@ -1641,11 +1746,36 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
         }
         const Patch *hdr = PL.finish();
-        hipLaunchKernelGGL(k_inc_prologue, dim3(1), dim3(1024), 0, s, hdr, (const char *)PL.buf.p, (int)PL.hdr.size(), Fold, F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p);
+        IncPrologue pro{ hdr, (const char *)PL.buf.p, (int)PL.hdr.size(), Fold, F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
+                         gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, nullptr, nullptr, 0 };
+        c.one_wait = 0;
+        const IncFlags fl = (!one && (iu || id)) ? IncFlags{ c.d_flags.p, nFr, c.d_tab.p + iu_off, iu ? iu_n : 0, c.d_tab.p + id_off, id ? id_n : 0 } : IncFlags{ nullptr, 0, nullptr, 0, nullptr, 0 };
+        if (tail_fast && !one) {                       // the refactorisation in the prologue's launch, the back substitution in launches of its own
+            hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), tail_refactor_lds(), s, pro, fl, c.dp, tstep, (const int *)nullptr, 0, (const int *)nullptr, 0,
+                               c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, UpdArgs{});
+        } else if (one) {
+            if (g_incprof_stamps) { c.h_kstamp.need(8 + PROF_SLOTS); memset(c.h_kstamp.p, 0, 8 * (8 + PROF_SLOTS)); pro.stamps = c.h_kstamp.p; }
+            if (g_opt.inc_one_spin) {                  // completion through a word in pinned memory: the host spins instead of sleeping in hipStreamSynchronize
+                if (!c.h_done.p) { c.h_done.need(16); c.h_done.p[0] = 0; }
+                c.done_seq = c.done_seq >= 0x7ffffff0 ? 1 : c.done_seq + 1;
+                pro.done = c.h_done.p; pro.seq = c.done_seq; c.one_wait = c.done_seq;
+            }
+            gp.h_out.need((size_t)3 * N);
+            const UpdArgs upd1{ c.d_perm.p, gp.d_lp.p, nullptr, gp.d_dx.p, gp.h_out.p, gp.h_dx.p, c.h_bad.p };
+            if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), one_lds, s, pro, fl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
+            else if (one_nt >= 512) hipLaunchKernelGGL(k_inc_one<512>, dim3(1), dim3(512), one_lds, s, pro, fl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
+            else hipLaunchKernelGGL(k_inc_one<256>, dim3(1), dim3(256), one_lds, s, pro, fl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
+        } else
+            hipLaunchKernelGGL(k_inc_prologue, dim3(1), dim3(1024), 0, s, pro, fl);
+    }
+    if (iu && !one) {
+        const int *list = c.d_tab.p + iu_off;
+        if (iu_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(iu_n), dim3(1024), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1);
+        else if (iu_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(iu_n), dim3(512), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1);
+        else hipLaunchKernelGGL(k_front_small<256>, dim3(iu_n), dim3(256), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1);
     }
     for (int l = 0; l < nLev; l++) {
-        if (lev_dirty[l].empty()) continue;
+        if (lev_dirty[l].empty() || iu || one) continue;
         if (mp && l >= 1) {
             if (l > 1) continue;
             const int *list = c.d_tab.p + mp_up_off;
@@ -1675,8 +1805,13 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     // of their own -- see pack_states_diff)
     gp.h_out.need((size_t)3 * N);
     const UpdArgs upd = batch ? UpdArgs{} : UpdArgs{ c.d_perm.p, gp.d_lp.p, nullptr, gp.d_dx.p, gp.h_out.p, gp.h_dx.p, c.h_bad.p };
-    bool rode = false;
-    for (int l = nLev - 1; l >= 0; l--) {
+    bool rode = one;
+    if (id && !one) {
+        if (g_opt.wave_backsolve && id_maxns <= BSW_MAX_NS) hipLaunchKernelGGL(k_backsolve_w, dim3(id_n), dim3(TPB), id_lds, s, c.dp, c.d_tab.p + id_off, c.d_pool.p, c.d_x.p, c.d_flags.p + nFr, c.d_bad.p, upd);
+        else hipLaunchKernelGGL((k_backsolve_t<true>), dim3(id_n), dim3(TPB), id_lds, s, c.dp, c.d_tab.p + id_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + nFr, 1, c.d_bad.p, upd);
+        rode = true;
+    }
+    for (int l = (one ? -1 : id ? (needed ? -1 : id_rest) : nLev - 1); l >= 0; l--) {
         if (mp && l >= 1) continue;
         if (batch) { launch_backsolve(c, dl[l], s, [](int) {}, []() {}); continue; }
         if (l >= I.nLev0 || needed) {
@@ -1703,6 +1838,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     }
     gp.new_states = gp.h_out.p;
     HIPCHECK(hipGetLastError());
+    if (nT > 0 && I.dirty[nFr - 1]) I.tail_ok = g_opt.inc_tail ? nFr - 1 : -1;      // (re)generated or refactorised by this step, in the padded layout
     for (int t : fd_dirty) I.dirty[t] = 0;
     // the pattern folded into the device structures (a later batch call compares against it)
     c.pat.resize((size_t)2 * F);
@@ -1870,7 +2006,9 @@ void batch_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
 struct IncProf {
     bool on = false; double acc[8] = { 0 }; long long n = 0;
     std::vector<std::array<float, 7>> steps;          // per step: the six phases + total (medians at exit)
-    IncProf() { const char *e = getenv("APRILSAM_AMD_INC_PROFILE"); on = e && *e == '1'; }
+    std::vector<std::array<float, 4>> kst;            // =2: phases of k_inc_one in us (patches, linearise, fronts, back substitution)
+    std::vector<std::array<float, 10>> fst;           //     ... and of its last front
+    IncProf() { const char *e = getenv("APRILSAM_AMD_INC_PROFILE"); on = e && (*e == '1' || *e == '2'); }
     ~IncProf() {
         if (!on || !n) return;
         fprintf(stderr, "aprilsam_amd inc profile over %lld steps (ms/step): pack %.4f model %.4f upload %.4f plan+enqueue %.4f d2h+sync %.4f writeback %.4f | total %.4f\n",
@@ -1884,6 +2022,26 @@ struct IncProf {
         }
         fprintf(stderr, "aprilsam_amd inc profile, MEDIANS (ms): pack %.4f model %.4f upload %.4f plan+enqueue %.4f d2h+sync %.4f writeback %.4f | total %.4f\n",
                 med[0], med[1], med[2], med[3], med[4], med[5], med[6]);
+        if (!kst.empty()) {
+            double km[4];
+            for (int k = 0; k < 4; k++) {
+                std::vector<float> v(kst.size());
+                for (size_t i = 0; i < kst.size(); i++) v[i] = kst[i][k];
+                std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+                km[k] = v[v.size() / 2];
+            }
+            fprintf(stderr, "aprilsam_amd inc profile, k_inc_one over %zu steps, MEDIANS (us): patches %.2f linearise %.2f fronts %.2f back substitution + update %.2f\n",
+                    kst.size(), km[0], km[1], km[2], km[3]);
+            double fm[10];
+            for (int k = 0; k < 10; k++) {
+                std::vector<float> v(fst.size());
+                for (size_t i = 0; i < fst.size(); i++) v[i] = fst[i][k];
+                std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+                fm[k] = v[v.size() / 2];
+            }
+            fprintf(stderr, "aprilsam_amd inc profile, last front of k_inc_one, MEDIANS (us): zero %.2f records %.2f work lists %.2f extend-add %.2f factorise %.2f store %.2f | "
+                    "own poses %.0f struct poses %.0f children %.0f work-list entries %.0f\n", fm[0], fm[1], fm[2], fm[3], fm[4], fm[5], fm[6], fm[7], fm[8], fm[9]);
+        }
     }
 };
 static IncProf g_incprof;
@@ -1949,14 +2107,31 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
         HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 16, hipMemcpyDeviceToHost, gp.stream));
     }
-    HIPCHECK(hipStreamSynchronize(gp.stream));
+    bool arrived = false;
+    if (reused && c.one_wait) {          // k_inc_one wrote everything else before this word; a launch that never answers is left to hipStreamSynchronize
+        const volatile int *w = c.h_done.p;
+        const double tw0 = now_ms();
+        for (int spins = 0; !(arrived = (*w == c.one_wait)); spins++) if ((spins & 1023) == 1023 && now_ms() - tw0 > 2.0) break;
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!arrived) HIPCHECK(hipStreamSynchronize(gp.stream));
+    c.one_wait = 0;
     const double tp5 = now_ms();
+    if (g_incprof.on && g_incprof_stamps && reused && c.h_kstamp.p && c.h_kstamp.p[4]) {
+        const long long *k = c.h_kstamp.p;
+        g_incprof.kst.push_back({ (float)(k[1] - k[0]) * 0.01f, (float)(k[2] - k[1]) * 0.01f, (float)(k[3] - k[2]) * 0.01f, (float)(k[4] - k[3]) * 0.01f });
+        const long long *f = k + 8;                  // last front of the step: zero, records, work lists, extend-add, factorisation, store; dims
+        g_incprof.fst.push_back({ (float)(f[4] - f[0]) * 0.01f, (float)(f[5] - f[4]) * 0.01f, f[6] ? (float)(f[6] - f[5]) * 0.01f : 0.f, (float)(f[1] - (f[6] ? f[6] : f[5])) * 0.01f,
+                                  (float)(f[2] - f[1]) * 0.01f, (float)(f[3] - f[2]) * 0.01f, (float)k[5], (float)k[6], (float)k[7], (float)f[7] });
+        c.h_kstamp.p[4] = 0;
+    }
     check_bad(c);
     c.st.error_code = 0;
     c.st.n_nodes = N; c.st.n_factors = F; c.st.symbolic_reused = reused;
     if (c.st.not_spd) {
         static bool warned = false;
         if (!warned) { fprintf(stderr, "aprilsam_amd: incremental system not positive definite; node states left untouched\n"); warned = true; }
+        c.inc.tail_ok = -1;                          // (a front stopped half-way: nothing to refactorise from)
         return;
     }
     // bookkeeping exactly as the reference: which poses solve_node visits / updates, start_over (refmodel.cpp)
@@ -2989,6 +3164,13 @@ int api_set_option(const char *name, double v) {
     else if (k == "tp_threads") g_opt.tp_threads = (int)v;
     else if (k == "lookahead") g_opt.lookahead = (int)v;
     else if (k == "inc_fast") g_opt.inc_fast = (int)v;
+    else if (k == "inc_multi") g_opt.inc_multi = (int)v;
+    else if (k == "inc_one") g_opt.inc_one = (int)v;
+    else if (k == "inc_one_up") g_opt.inc_one_up = std::max(1, (int)v);
+    else if (k == "inc_one_dn") g_opt.inc_one_dn = std::max(1, (int)v);
+    else if (k == "inc_one_threads") g_opt.inc_one_threads = (int)v;
+    else if (k == "inc_one_spin") g_opt.inc_one_spin = (int)v;
+    else if (k == "inc_tail") g_opt.inc_tail = (int)v;
     else if (k == "block_factor") g_opt.block_factor = (int)v;
     else if (k == "pin_last") g_opt.pin_last = (int)v;
     else if (k == "fused_panel") g_opt.fused_panel = (int)v;
@@ -3006,7 +3188,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "mem_cap_mb") g_opt.mem_cap_mb = (int)v;
     else return -1;
     // host-side policies that no launch table or captured graph depends on
-    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "batch_extend",
+    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "inc_multi", "inc_one", "inc_one_up", "inc_one_dn", "inc_one_threads", "inc_one_spin", "batch_extend",
                                              "extend_tail_fronts", "mem_cap_mb", "medium_lds_kb" };
     bool policy = false;
     for (const char *q : no_replan) policy = policy || k == q;

@@ -265,6 +265,8 @@ void aprilsam_amd_clear_error(void);
  *   "pin_last"          k > 0: the k newest poses are kept out of the nested dissection and form the root front ("recent
  *                       poses last", cf. aprilsam.c:1021-1098); default 0, measured effect in profiles/r02_inc_hist.json
  *   "inc_fast"          0 = every incremental step re-plans (default 1: frozen base plan + dirty root paths)
+ *   "inc_multi"         0 = incremental steps launch their fronts / back substitution level by level (default 1: one multi-level
+ *                       launch per direction, fronts synchronised by dependency flags)
  *   "persist"           1 (default): the top levels of the elimination tree -- as many as hold at most "persist_max_fronts"
  *                       (default 240) single-workgroup fronts -- run as ONE launch per sweep, fronts synchronised by
  *                       per-front dependency flags; 0 = one launch per level
