@@ -17,6 +17,7 @@ struct Options {
     int inc_one = 1;              // ... and a step that regenerates at most inc_one_up fronts and walks at most inc_one_dn as ONE single-workgroup launch
     int inc_one_up = 3, inc_one_dn = 4, inc_one_threads = 512, inc_one_spin = 1;
     int inc_tail = 1;             // ... and steps whose factors touch the last few poses of the last tail front alone re-factorise its trailing columns only
+    int inc_inline = 1;           // ... a small step's table / factor / state patches travel in the kernel arguments instead of being read across PCIe
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
     int small_threads = 1024;     // workgroup size of k_front_small (256 / 512 / 1024) on latency-bound levels ...
     int tp_threads = 512;         // ... and on throughput levels (>= tp_fronts fronts)

@@ -81,6 +81,7 @@ static void load_env_options() {
         v = g_opt.inc_one_threads; envd("APRILSAM_AMD_INC_ONE_THREADS", &v); g_opt.inc_one_threads = (int)v;
         v = g_opt.inc_one_spin; envd("APRILSAM_AMD_INC_ONE_SPIN", &v); g_opt.inc_one_spin = (int)v;
         v = g_opt.inc_tail; envd("APRILSAM_AMD_INC_TAIL", &v); g_opt.inc_tail = (int)v;
+        v = g_opt.inc_inline; envd("APRILSAM_AMD_INC_INLINE", &v); g_opt.inc_inline = (int)v;
         v = g_opt.block_factor; envd("APRILSAM_AMD_BLOCK_FACTOR", &v); g_opt.block_factor = (int)v;
         v = g_opt.fused_panel; envd("APRILSAM_AMD_FUSED_PANEL", &v); g_opt.fused_panel = (int)v;
         v = g_opt.persist; envd("APRILSAM_AMD_PERSIST", &v); g_opt.persist = (int)v;
@@ -508,6 +509,7 @@ struct Context {
     DBuf<double> d_pool, d_H, d_x, d_diag;   // d_diag: factored diagonal blocks of the current panel step, one per active big front
     DBuf<int> d_bad;
     HBuf<int> h_bad;
+    IncPrologue pro{}; InlinePatches inl{};       // arguments of the incremental step's first kernel
     HBuf<long long> h_kstamp; HBuf<int> h_done; int done_seq = 0, one_wait = 0;      // k_inc_one: phase stamps (profile), completion word the host spins on
     std::vector<double> h_lambda;
     aprilsam_amd_stats_t st{};
@@ -947,6 +949,9 @@ static void set_small_attr() {
         HIPCHECK(hipFuncSetAttribute((const void *)k_assemble_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_block_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_block_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_inc_one<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_inc_one<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHECK(hipFuncSetAttribute((const void *)k_inc_one<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
 }
 
@@ -1344,13 +1349,114 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     if (!batch && g_opt.inc_tail && g_opt.inc_multi && g_opt.persist && !I.t_first.empty() && I.tail_ok == nF0 + (int)I.t_first.size() - 1 && F > Fold) {
         const int first = I.t_first.back(), n_old = I.t_cnt.back(), n_new = n_old + (N - std::max(Nold, Nb));
         int lo = first + n_old;                        // (poses added by this step: all of their columns are new)
-        bool ok = n_new <= TAIL_POSES && I.E.back().empty();
+        bool ok = n_new <= TAIL_POSES && I.E.back().empty() && F - Fold <= TAIL_MAXF;
         for (int f = Fold; f < F && ok; f++) {
             const int a = fa[f], b = fb[f];
             ok = a >= first && (b < 0 || b >= first);
             lo = std::min(lo, b >= 0 ? std::min(a, b) : a);
         }
         if (ok && n_new - (lo - first) <= TAILK) { tail_fast = true; tstep = TailStep{ nF0 + (int)I.t_first.size() - 1, lo - first, n_old }; }
+    }
+    // ... and when the reference's walk stays on a short root path, the whole step is decided here, without the general
+    // machinery below (whose cost grows with the number of fronts and levels): one k_inc_one launch
+    if (tail_fast && needed && g_opt.inc_one && g_opt.wave_backsolve && patch_states && F <= gp.F_cap) {
+        const int T = tstep.t, first = I.t_first.back(), nT0 = (int)I.t_first.size(), nFr0 = nF0 + nT0;
+        const int n_new = I.t_cnt.back() + (N - std::max(Nold, Nb)), nph = TAIL_POSES - n_new;
+        auto nsb_now = [&](int t) { return t == T ? n_new : (t >= nF0 ? I.t_cnt[t - nF0] : P.f_nsb[t]); };
+        auto nub_now = [&](int t) { return t == T ? nph : I.cur_nub[t]; };
+        // the fronts of the visited poses and their ancestors, top level first
+        std::vector<int> &lst = I.st_ids; lst.clear();
+        I.need.assign(nFr0, 0);
+        bool fits = true; size_t lds = tail_refactor_lds(); int maxns = 0;
+        for (const RefModel::Visit &v : *needed) {
+            int t = v.node >= first ? T : (v.node >= Nb ? I.tf_of[v.node - Nb] : I.pos_front[P.pos[v.node]]);
+            while (t >= 0 && !I.need[t]) { I.need[t] = 1; lst.push_back(t); t = I.parent[t]; }
+        }
+        fits = !lst.empty() && (int)lst.size() <= g_opt.inc_one_dn;
+        if (fits) {
+            std::sort(lst.begin(), lst.end(), [&](int x, int y) { return I.f_level[x] != I.f_level[y] ? I.f_level[x] > I.f_level[y] : x < y; });
+            for (int t : lst) { lds = std::max(lds, backsolve_lds(3 * (nsb_now(t) + nub_now(t)), 3 * nsb_now(t), true)); maxns = std::max(maxns, 3 * nsb_now(t)); }
+            fits = lds <= 160 * 1024 && maxns <= BSW_MAX_NS && I.tab_used + (long long)lst.size() <= (long long)c.d_tab.cap &&
+                   (size_t)9 * (I.slots_used + 5 * (F - Fold)) <= c.d_H.cap && (size_t)N <= c.d_perm.cap;
+        }
+        if (fits) {
+            // bookkeeping, as sections 0-2 below do it for this case
+            for (int k = std::max(Nold, Nb); k < N; k++) { I.t_cnt.back()++; I.tf_of.push_back(T); }
+            std::vector<int> &new_slot_blk = I.st_sb, &new_slot_rhs = I.st_sr; std::vector<unsigned char> &new_swap = I.st_sw;
+            new_slot_blk.resize((size_t)3 * (F - Fold)); new_slot_rhs.resize((size_t)2 * (F - Fold)); new_swap.resize(F - Fold);
+            c.inc_slot_blk.resize((size_t)3 * (F - I.Fb), -1); c.inc_slot_rhs.resize((size_t)2 * (F - I.Fb), -1);
+            for (int f = Fold; f < F; f++) {
+                I.xfac[T].push_back(f);
+                for (int k = 0; k < 3; k++) new_slot_blk[(size_t)3 * (f - Fold) + k] = c.inc_slot_blk[(size_t)3 * (f - I.Fb) + k] = I.slots_used++;
+                for (int k = 0; k < 2; k++) new_slot_rhs[(size_t)2 * (f - Fold) + k] = c.inc_slot_rhs[(size_t)2 * (f - I.Fb) + k] = I.slots_used++;
+                new_swap[f - Fold] = fb[f] >= 0 && fa[f] < fb[f];
+            }
+            FrontDesc &D = I.fd[T];
+            D.nsb = n_new; D.nub = nph; I.cur_nub[T] = nph;
+            I.recs_stale = T; I.tail_ok = T;
+            c.st.reserved0 = 1;
+            // patches
+            PatchList &PL = c.patches;
+            PL.reset();
+            const int f0 = gp.F_on_device;
+            if (F > f0) {
+                PL.add(gp.d_fa.p + f0, gp.h_fa.p + f0, (size_t)(F - f0) * 4); PL.add(gp.d_fb.p + f0, gp.h_fb.p + f0, (size_t)(F - f0) * 4);
+                PL.add(gp.d_z.p + (size_t)3 * f0, gp.h_z.p + (size_t)3 * f0, (size_t)(F - f0) * 24);
+                PL.add(gp.d_W.p + (size_t)9 * f0, gp.h_W.p + (size_t)9 * f0, (size_t)(F - f0) * 72);
+                gp.F_on_device = F;
+            }
+            PL.add(c.d_tab.p + I.tab_used, lst.data(), lst.size() * 4);
+            PL.add(c.d_fd.p + T, &D, sizeof(FrontDesc));
+            PL.add((int *)c.dp.slot_blk + (size_t)3 * Fold, new_slot_blk.data(), new_slot_blk.size() * 4);
+            PL.add((int *)c.dp.slot_rhs + (size_t)2 * Fold, new_slot_rhs.data(), new_slot_rhs.size() * 4);
+            PL.add(c.d_swap.p + Fold, new_swap.data(), new_swap.size());
+            if (N > Nold) {
+                int ids[TAILK + 1]; double zeros[TAILK + 1];
+                const int nn = N - Nold;              // (<= TAILK: the new poses are among the trailing columns)
+                for (int i = 0; i < nn; i++) { ids[i] = Nold + i; zeros[i] = 0.0; }
+                PL.add(c.d_pos.p + Nold, ids, (size_t)nn * 4);
+                PL.add(c.d_perm.p + Nold, ids, (size_t)nn * 4);
+                PL.add(c.d_lambda.p + Nold, zeros, (size_t)nn * 8);       // no Tikhonov term on poses added incrementally (aprilsam.c:508-542)
+                c.lambda_N = -1;
+                P.perm.resize(N); P.pos.resize(N);
+                for (int i = Nold; i < N; i++) { P.perm[i] = i; P.pos[i] = i; }
+            }
+            for (int i : gp.changed) {
+                PL.add(gp.d_state.p + (size_t)3 * i, gp.h_state.p + (size_t)3 * i, 24);
+                PL.add(gp.d_lp.p + (size_t)3 * i, gp.h_lp.p + (size_t)3 * i, 24);
+            }
+            set_small_attr();
+            const Patch *hdr = PL.finish();
+            IncPrologue &pro = c.pro;
+            pro.patches = hdr; pro.payload = (const char *)PL.buf.p; pro.n_patch = (int)PL.hdr.size(); pro.f_begin = Fold; pro.f_end = F;
+            pro.fa = gp.d_fa.p; pro.fb = gp.d_fb.p; pro.Z = gp.d_z.p; pro.Wm = gp.d_W.p; pro.lp = gp.d_lp.p; pro.st = gp.d_state.p; pro.swp = c.d_swap.p;
+            pro.slot_blk = c.dp.slot_blk; pro.slot_rhs = c.dp.slot_rhs; pro.Hc = c.d_H.p; pro.bad = c.d_bad.p; pro.stamps = nullptr; pro.done = nullptr; pro.seq = 0;
+            pro.inl = g_opt.inc_inline && PL.hdr.size() <= (size_t)INL_PATCHES && PL.used <= (size_t)INL_BYTES;
+            if (pro.inl) { memcpy(c.inl.hdr, PL.hdr.data(), PL.hdr.size() * sizeof(Patch)); memcpy(c.inl.pay, PL.buf.p, PL.used); }
+            c.one_wait = 0;
+            if (g_incprof_stamps) { c.h_kstamp.need(8 + PROF_SLOTS); memset(c.h_kstamp.p, 0, 8 * (8 + PROF_SLOTS)); pro.stamps = c.h_kstamp.p; }
+            if (g_opt.inc_one_spin) {
+                if (!c.h_done.p) { c.h_done.need(16); c.h_done.p[0] = 0; }
+                c.done_seq = c.done_seq >= 0x7ffffff0 ? 1 : c.done_seq + 1;
+                pro.done = c.h_done.p; pro.seq = c.done_seq; c.one_wait = c.done_seq;
+            }
+            gp.h_out.need((size_t)3 * N);
+            const UpdArgs upd1{ c.d_perm.p, gp.d_lp.p, nullptr, gp.d_dx.p, gp.h_out.p, gp.h_dx.p, c.h_bad.p };
+            const IncFlags nofl{ nullptr, 0, nullptr, 0, nullptr, 0 };
+            const int *dn = c.d_tab.p + I.tab_used; const int n_dn = (int)lst.size();
+            const int one_nt = g_opt.inc_one_threads >= 1024 ? 1024 : g_opt.inc_one_threads >= 512 ? 512 : 256;
+            if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, g_opt.block_factor, c.d_x.p, upd1);
+            else if (one_nt >= 512) hipLaunchKernelGGL(k_inc_one<512>, dim3(1), dim3(512), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, g_opt.block_factor, c.d_x.p, upd1);
+            else hipLaunchKernelGGL(k_inc_one<256>, dim3(1), dim3(256), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, g_opt.block_factor, c.d_x.p, upd1);
+            gp.mirror_sync = true;
+            gp.new_states = gp.h_out.p;
+            HIPCHECK(hipGetLastError());
+            c.pat.resize((size_t)2 * F);
+            for (int f = Fold; f < F; f++) { c.pat[2 * f] = fa[f]; c.pat[2 * f + 1] = fb[f]; }
+            c.patN = N;
+            c.st.n_fronts = nFr0; c.st.n_levels = I.nLev0 + nT0;
+            return true;
+        }
     }
     // (any other way of factorising that front reads its destination records: they are brought up to date first)
     if (!tail_fast && I.recs_stale >= 0) I.dirty[I.recs_stale] = 1;
@@ -1746,12 +1852,16 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             hipLaunchKernelGGL(k_load_states_lp, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.h_lp.p, gp.d_state.p, gp.d_lp.p, c.d_bad.p);
         }
         const Patch *hdr = PL.finish();
-        IncPrologue pro{ hdr, (const char *)PL.buf.p, (int)PL.hdr.size(), Fold, F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                         gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, nullptr, nullptr, 0 };
+        IncPrologue &pro = c.pro;                      // (2.7 KB with the inline patch area: filled in place)
+        pro.patches = hdr; pro.payload = (const char *)PL.buf.p; pro.n_patch = (int)PL.hdr.size(); pro.f_begin = Fold; pro.f_end = F;
+        pro.fa = gp.d_fa.p; pro.fb = gp.d_fb.p; pro.Z = gp.d_z.p; pro.Wm = gp.d_W.p; pro.lp = gp.d_lp.p; pro.st = gp.d_state.p; pro.swp = c.d_swap.p;
+        pro.slot_blk = c.dp.slot_blk; pro.slot_rhs = c.dp.slot_rhs; pro.Hc = c.d_H.p; pro.bad = c.d_bad.p; pro.stamps = nullptr; pro.done = nullptr; pro.seq = 0;
+        pro.inl = g_opt.inc_inline && PL.hdr.size() <= (size_t)INL_PATCHES && PL.used <= (size_t)INL_BYTES;
+        if (pro.inl) { memcpy(c.inl.hdr, PL.hdr.data(), PL.hdr.size() * sizeof(Patch)); memcpy(c.inl.pay, PL.buf.p, PL.used); }
         c.one_wait = 0;
         const IncFlags fl = (!one && (iu || id)) ? IncFlags{ c.d_flags.p, nFr, c.d_tab.p + iu_off, iu ? iu_n : 0, c.d_tab.p + id_off, id ? id_n : 0 } : IncFlags{ nullptr, 0, nullptr, 0, nullptr, 0 };
         if (tail_fast && !one) {                       // the refactorisation in the prologue's launch, the back substitution in launches of its own
-            hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), tail_refactor_lds(), s, pro, fl, c.dp, tstep, (const int *)nullptr, 0, (const int *)nullptr, 0,
+            hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), tail_refactor_lds(), s, pro, fl, c.inl, c.dp, tstep, (const int *)nullptr, 0, (const int *)nullptr, 0,
                                c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, UpdArgs{});
         } else if (one) {
             if (g_incprof_stamps) { c.h_kstamp.need(8 + PROF_SLOTS); memset(c.h_kstamp.p, 0, 8 * (8 + PROF_SLOTS)); pro.stamps = c.h_kstamp.p; }
@@ -1762,11 +1872,11 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             }
             gp.h_out.need((size_t)3 * N);
             const UpdArgs upd1{ c.d_perm.p, gp.d_lp.p, nullptr, gp.d_dx.p, gp.h_out.p, gp.h_dx.p, c.h_bad.p };
-            if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), one_lds, s, pro, fl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
-            else if (one_nt >= 512) hipLaunchKernelGGL(k_inc_one<512>, dim3(1), dim3(512), one_lds, s, pro, fl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
-            else hipLaunchKernelGGL(k_inc_one<256>, dim3(1), dim3(256), one_lds, s, pro, fl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
+            if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
+            else if (one_nt >= 512) hipLaunchKernelGGL(k_inc_one<512>, dim3(1), dim3(512), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
+            else hipLaunchKernelGGL(k_inc_one<256>, dim3(1), dim3(256), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
         } else
-            hipLaunchKernelGGL(k_inc_prologue, dim3(1), dim3(1024), 0, s, pro, fl);
+            hipLaunchKernelGGL(k_inc_prologue, dim3(1), dim3(1024), 0, s, pro, fl, c.inl);
     }
     if (iu && !one) {
         const int *list = c.d_tab.p + iu_off;
@@ -3171,6 +3281,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "inc_one_threads") g_opt.inc_one_threads = (int)v;
     else if (k == "inc_one_spin") g_opt.inc_one_spin = (int)v;
     else if (k == "inc_tail") g_opt.inc_tail = (int)v;
+    else if (k == "inc_inline") g_opt.inc_inline = (int)v;
     else if (k == "block_factor") g_opt.block_factor = (int)v;
     else if (k == "pin_last") g_opt.pin_last = (int)v;
     else if (k == "fused_panel") g_opt.fused_panel = (int)v;
@@ -3188,7 +3299,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "mem_cap_mb") g_opt.mem_cap_mb = (int)v;
     else return -1;
     // host-side policies that no launch table or captured graph depends on
-    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "inc_multi", "inc_one", "inc_one_up", "inc_one_dn", "inc_one_threads", "inc_one_spin", "batch_extend",
+    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "inc_multi", "inc_one", "inc_one_up", "inc_one_dn", "inc_one_threads", "inc_one_spin", "inc_inline", "batch_extend",
                                              "extend_tail_fronts", "mem_cap_mb", "medium_lds_kb" };
     bool policy = false;
     for (const char *q : no_replan) policy = policy || k == q;
