@@ -15,10 +15,15 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 
 namespace asam {
 namespace {
@@ -115,10 +120,97 @@ struct Dinic {
     }
 };
 
-// per-vertex working state of one worker
+// Worker threads of the planner, created once per process and parked between plans (creating up to 16 threads per plan
+// cost about a tenth of a cold M3500 plan).  run(n, fn): fn(0..n-1) on the workers AND the caller, back when all are done;
+// the caller alone finishes the job if no worker ever shows up (a forked child has none).  After a job a worker spins for
+// a short while before it sleeps: inside one plan the jobs follow each other within tens of microseconds.
+// (no PAUSE in the wait loops: under a hypervisor with pause-loop exiting a spinning virtual CPU is taken off its core for a
+// whole time slice, which turns a wait of microseconds into one of hundreds; the waits here are short and bounded)
+static inline void cpu_relax() { asm volatile("" ::: "memory"); }
+class PlanPool {
+    // Two job slots used alternately (job number g lives in slot g & 1).  Picking a job up takes no lock -- a mutex handed
+    // from worker to worker costs a futex wake per hand-over, which on a virtual machine is longer than the jobs -- so a
+    // slot is guarded Dekker-style: a worker announces "inside job g" (state) and then checks the slot's tag; the caller
+    // closes the slot (tag = -1), then waits for every "inside" announcement of its previous use to be withdrawn, then refills it.
+    struct alignas(128) Job { std::function<void(int, int)> fn; int n = 0; std::atomic<int> next{ 0 }, done{ 0 }; std::atomic<long long> tag{ -1 }; };
+    struct alignas(128) WState { std::atomic<long long> v{ 0 }; };      // 2 g + 1: inside job g; even: not inside any
+    Job slot[2];
+    std::unique_ptr<WState[]> state;
+    std::atomic<long long> gen{ 0 };
+    std::mutex mu; std::condition_variable cv; std::atomic<int> sleepers{ 0 };     // only for workers idle long enough to go to sleep
+    std::atomic<int> sessions{ 0 };            // plans in progress: their jobs follow each other within microseconds, workers stay awake
+    std::mutex one_caller;                     // (plans of different params may be built on different application threads)
+    int nworkers = 0;
+    static void drain(Job &j, int who) { for (int i; (i = j.next.fetch_add(1, std::memory_order_acq_rel)) < j.n;) { j.fn(i, who); j.done.fetch_add(1, std::memory_order_acq_rel); } }
+    void worker(int w) {
+        long long seen = 0;
+        for (;;) {
+            long long g = gen.load(std::memory_order_acquire);
+            if (g == seen) {
+                while ((g = gen.load(std::memory_order_acquire)) == seen && sessions.load(std::memory_order_acquire) > 0) cpu_relax();
+                if (g == seen) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    sleepers.fetch_add(1, std::memory_order_seq_cst);
+                    cv.wait(lk, [&] { return gen.load(std::memory_order_seq_cst) != seen || sessions.load(std::memory_order_seq_cst) > 0; });
+                    sleepers.fetch_sub(1, std::memory_order_seq_cst);
+                    g = gen.load(std::memory_order_acquire);
+                    if (g == seen) continue;   // (woken for a session: back to the polling loop)
+                }
+            }
+            seen = g;
+            Job &j = slot[g & 1];
+            state[w].v.store(2 * g + 1, std::memory_order_seq_cst);
+            if (j.tag.load(std::memory_order_seq_cst) == g) drain(j, w + 1);
+            state[w].v.store(2 * g, std::memory_order_seq_cst);
+        }
+    }
+public:
+    explicit PlanPool(int workers) : state(new WState[std::max(1, workers)]), nworkers(workers) {
+        for (int i = 0; i < workers; i++) std::thread([this, i] { worker(i); }).detach();
+    }
+    int workers() const { return nworkers; }
+    // f(i, who) for i < cnt; who = 0 for the calling thread, w + 1 for worker w (at most one item at a time per `who`)
+    void run(int cnt, const std::function<void(int, int)> &f) {
+        if (cnt <= 0) return;
+        if (cnt == 1 || nworkers == 0) { for (int i = 0; i < cnt; i++) f(i, 0); return; }
+        std::lock_guard<std::mutex> only(one_caller);
+        const long long g = gen.load(std::memory_order_acquire) + 1;
+        Job &j = slot[g & 1];
+        j.tag.store(-1, std::memory_order_seq_cst);                              // closed: nobody new gets in ...
+        for (int w = 0; w < nworkers; w++) while (state[w].v.load(std::memory_order_seq_cst) == 2 * (g - 2) + 1) cpu_relax();     // ... and its last users are out
+        j.fn = f; j.n = cnt; j.next.store(0, std::memory_order_relaxed); j.done.store(0, std::memory_order_relaxed);
+        j.tag.store(g, std::memory_order_seq_cst);
+        gen.store(g, std::memory_order_seq_cst);
+        if (sleepers.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
+        drain(j, 0);
+        while (j.done.load(std::memory_order_acquire) < cnt) cpu_relax();
+        j.fn = nullptr;                        // (a worker arriving now finds next >= n and never calls it; fn is only read for an index < n)
+    }
+    // a plan in progress: wakes the workers once (without waiting for them) and keeps them polling until it is over
+    struct Session {
+        PlanPool *p;
+        explicit Session(PlanPool *pool) : p(pool) {
+            if (!p) return;
+            p->sessions.fetch_add(1, std::memory_order_seq_cst);
+            if (p->sleepers.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(p->mu); p->cv.notify_all(); }
+        }
+        ~Session() { if (p) p->sessions.fetch_sub(1, std::memory_order_seq_cst); }
+    };
+    static PlanPool &get() {
+        static PlanPool *pool = [] {
+            unsigned hw = std::thread::hardware_concurrency();
+            int nt = std::max(1, std::min(16, hw ? (int)hw : 1));
+            if (const char *e = getenv("APRILSAM_AMD_PLAN_THREADS")) nt = std::max(1, atoi(e));
+            return new PlanPool(nt - 1);       // never destroyed: its threads are parked for the life of the process
+        }();
+        return *pool;
+    }
+};
+
+// labels of the regions a worker has in hand (vertices outside them keep label 0) ...
 struct Shared {
-    std::vector<int> label, dist, loc; std::vector<char> side; int next_label = 0;
-    explicit Shared(int N) : label(N, 0), dist(N, -1), loc(N, -1), side(N, 0) {}
+    std::vector<int> label; int next_label = 0;
+    explicit Shared(int N) : label(N, 0) {}
 };
 struct Item { std::vector<int> verts; int parent; };
 
@@ -131,13 +223,26 @@ struct Dissector {
     // Per-vertex scratch of this worker (every access to dist / loc / side of a neighbour is guarded by
     // "label[neighbour] == my region"; vertices outside the worker's regions keep label 0).
     Shared &sh;
+    std::vector<int> dist_, loc_; std::vector<char> side_;      // ... and the per-vertex scratch of this evaluator
     int *dist, *loc; char *side;
     Dinic dinic;                // scratch of refine_band
     HopcroftKarp hk_;           // scratch of cut_to_separator (buffers reused across the hundreds of calls of one plan)
-    std::vector<int> B0_, B1_, band_; std::vector<char> inL_, inR_; std::vector<std::pair<double, int>> pr_;
+    std::vector<int> B0_, B1_, band_, order_; std::vector<char> inL_, inR_; std::vector<std::pair<double, int>> pr_;
 
     Dissector(int N_, const std::vector<int> &ap_, const std::vector<int> &ai_, const double *xy_, int leaf_, NDTree &t, Shared &sh_)
-        : N(N_), ap(ap_), ai(ai_), xy(xy_), leaf(leaf_), tree(t), sh(sh_), dist(sh_.dist.data()), loc(sh_.loc.data()), side(sh_.side.data()) {}
+        : N(N_), ap(ap_), ai(ai_), xy(xy_), leaf(leaf_), tree(t), sh(sh_), dist_(N_, -1), loc_(N_, -1), side_(N_, 0),
+          dist(dist_.data()), loc(loc_.data()), side(side_.data()) {}
+    // Regions of at least par_min vertices (the top of the tree, which one thread walks alone) have their candidate splits
+    // and their refinements evaluated side by side: helper evaluators share this dissector's labels (read only while they
+    // run) and own their scratch; every candidate is computed by the same code on the same inputs as in the serial order,
+    // so the tree does not depend on the number of threads.
+    size_t par_min = 0; PlanPool *pool = nullptr;
+    std::vector<std::unique_ptr<Dissector>> helpers;
+    Dissector &helper(int k) {
+        if (k == 0) return *this;
+        while ((int)helpers.size() < k) helpers.emplace_back(new Dissector(N, ap, ai, xy, leaf, tree, sh));
+        return *helpers[k - 1];
+    }
     int lab(int v) const { return sh.label[v]; }
     void set_lab(int v, int L) { sh.label[v] = L; }
     int new_label() { return ++sh.next_label; }
@@ -162,7 +267,8 @@ struct Dissector {
         }
     }
 
-    struct Split { std::vector<int> S, P0, P1; double cost = 1e300; bool ok = false; };
+    struct alignas(128) Split { std::vector<int> S, P0, P1; double cost = 1e300; bool ok = false; };      // (own cache lines: candidates are filled side by side)
+    Split cand_[8], ref_out_;   // candidates of the region being split / result of a refinement (buffers reused from region to region)
 
     // side[v] in {0,1} given for all v of comp: edge cut -> minimum vertex separator
     void cut_to_separator(const std::vector<int> &comp, int L, Split &out) {
@@ -244,7 +350,7 @@ struct Dissector {
             if (a0) { fl.add(SRC, 2 * i, INF); core0 = true; }
             if (a1) { fl.add(2 * i + 1, SNK, INF); core1 = true; }
         }
-        Split out;
+        Split &out = ref_out_; out.S.clear(); out.P0.clear(); out.P1.clear(); out.ok = false; out.cost = 1e300;
         if (core0 && core1) {
             fl.run(SRC, SNK);
             fl.bfs(SRC, SNK);                             // residual reachability in fl.lvl
@@ -257,11 +363,11 @@ struct Dissector {
             score(comp, out);
         }
         for (int v : band) { dist[v] = -1; loc[v] = -1; }
-        if (out.ok && out.cost < sp.cost) sp = std::move(out);
+        if (out.ok && out.cost < sp.cost) { sp.S.swap(out.S); sp.P0.swap(out.P0); sp.P1.swap(out.P1); sp.cost = out.cost; sp.ok = true; }
     }
 
     void split_bfs(const std::vector<int> &comp, int L, Split &out) {
-        std::vector<int> order;
+        std::vector<int> &order = order_;
         int s = comp[0];
         for (int sweep = 0; sweep < 2; sweep++) {           // pseudo-peripheral start
             bfs(s, L, order);
@@ -326,26 +432,31 @@ struct Dissector {
         }
     }
 
-    template <class Stack>
-    void handle(std::vector<int> &comp, int L, int parent, Stack &stack) {
-        if ((int)comp.size() <= leaf) { for (int v : comp) set_lab(v, -1); new_node(std::move(comp), parent); return; }
-        Split cand[8];
-        split_geometric(comp, L, cand[0]);
+    // the split of one connected region of more than `leaf` vertices (null: none found, the region stays a dense node).  A pure
+    // function of the region and the graph: it does not touch the tree, and leaves this evaluator's scratch as it found it.
+    Split *best_split(const std::vector<int> &comp, int L) {
+        Split (&cand)[8] = cand_;
+        for (Split &c : cand) { c.ok = false; c.cost = 1e300; }
         static const int T_DIRS = getenv("APRILSAM_AMD_ND_DIRS") ? atoi(getenv("APRILSAM_AMD_ND_DIRS")) : 8;
         static const int T_REF = getenv("APRILSAM_AMD_ND_REF") ? atoi(getenv("APRILSAM_AMD_ND_REF")) : 4;
         static const int T_BAND = getenv("APRILSAM_AMD_ND_BAND") ? atoi(getenv("APRILSAM_AMD_ND_BAND")) : 2;
-        if ((int)comp.size() > T_DIRS * leaf) {                         // the extra directions only pay near the top of the tree
-            split_geometric(comp, L, cand[1], 1.5707963267948966);      // orthogonal axis
-            split_geometric(comp, L, cand[2], 0.7853981633974483);      // diagonal
-        }
         static const int T_MORE = getenv("APRILSAM_AMD_ND_MORE") ? atoi(getenv("APRILSAM_AMD_ND_MORE")) : 0;      // region size (x leaf) above which 4 more directions are tried
-        if (T_MORE > 0 && (int)comp.size() > T_MORE * leaf) {
-            split_geometric(comp, L, cand[4], 2.356194490192345);       // other diagonal
-            split_geometric(comp, L, cand[5], 0.39269908169872414);
-            split_geometric(comp, L, cand[6], 1.1780972450961724);
-            split_geometric(comp, L, cand[7], 1.9634954084936207);
+        // candidates: slot 3 = the BFS level structure (the longest job: first), the others geometric bisections
+        struct Job { int slot; double rot; } jobs[8]; int nj = 0;
+        jobs[nj++] = { 3, 0.0 };
+        jobs[nj++] = { 0, 0.0 };                                         // principal axis
+        if ((int)comp.size() > T_DIRS * leaf) {                         // the extra directions only pay near the top of the tree
+            jobs[nj++] = { 1, 1.5707963267948966 };                      // orthogonal axis
+            jobs[nj++] = { 2, 0.7853981633974483 };                      // diagonal
         }
-        split_bfs(comp, L, cand[3]);
+        if (T_MORE > 0 && (int)comp.size() > T_MORE * leaf) {
+            jobs[nj++] = { 4, 2.356194490192345 };                       // other diagonal
+            jobs[nj++] = { 5, 0.39269908169872414 }; jobs[nj++] = { 6, 1.1780972450961724 }; jobs[nj++] = { 7, 1.9634954084936207 };
+        }
+        const bool par = pool && par_min > 0 && comp.size() >= par_min;
+        auto eval = [&](Dissector &d, const Job &jb) { if (jb.slot == 3) d.split_bfs(comp, L, cand[3]); else d.split_geometric(comp, L, cand[jb.slot], jb.rot); };
+        if (par) { helper(nj - 1); pool->run(nj, [&](int k, int) { eval(helper(k), jobs[k]); }); }
+        else for (int k = 0; k < nj; k++) eval(*this, jobs[k]);
         Split *best = nullptr, *second = nullptr;
         for (Split &c : cand) {
             if (!c.ok) continue;
@@ -353,18 +464,59 @@ struct Dissector {
             else if (!second || c.cost < second->cost) second = &c;
         }
         if (best && (int)comp.size() > T_REF * leaf) {
-            for (Split *c : { best, second }) {
-                if (!c || (c == second && second->cost > 1.25 * best->cost)) continue;
-                for (int pass = 0; pass < 2; pass++) { double before = c->cost; refine_band(comp, L, *c, T_BAND); if (c->cost >= before) break; }
+            auto refine = [&](Dissector &d, Split *c) { for (int pass = 0; pass < 2; pass++) { double before = c->cost; d.refine_band(comp, L, *c, T_BAND); if (c->cost >= before) break; } };
+            if (par && second) {
+                // the runner-up is refined at the same time; the rule "only if within 25 % of the REFINED best" is applied afterwards
+                // (a runner-up outside it cannot win refined or not, so its refinement is simply ignored: same result as in sequence)
+                const double second_cost0 = second->cost;
+                helper(1);
+                pool->run(2, [&](int k, int) { refine(helper(k), k == 0 ? best : second); });
+                if (second_cost0 > 1.25 * best->cost) second = nullptr;
+            } else {
+                for (Split *c : { best, second }) {
+                    if (!c || (c == second && second->cost > 1.25 * best->cost)) continue;
+                    refine(*this, c);
+                }
             }
             if (second && second->cost < best->cost) best = second;
         }
-        if (!best) { for (int v : comp) set_lab(v, -1); new_node(std::move(comp), parent); return; }   // dense region
+        return best;
+    }
+    template <class Stack>
+    void handle(std::vector<int> &comp, int L, int parent, Stack &stack) {
+        Split *best = (int)comp.size() <= leaf ? nullptr : best_split(comp, L);
+        if (!best) { for (int v : comp) set_lab(v, -1); new_node(std::move(comp), parent); return; }   // leaf / dense region
         for (int v : best->S) set_lab(v, -1);
         int t = new_node(std::move(best->S), parent);
         stack.push_back({ std::move(best->P0), t });
         stack.push_back({ std::move(best->P1), t });
     }
+
+    // One region of the top of the tree, without touching the tree: its connected components in the order run() meets them,
+    // each either a leaf / dense node or a split into separator + two parts.  nested_dissection computes these level by level
+    // (regions of a level side by side) and creates the tree nodes afterwards, in the order run() would have.
+    struct CompResult { bool leaf = true; std::vector<int> verts, P0, P1; int c0 = -1, c1 = -1; };      // verts: the leaf, or the separator; c0 / c1: results of the parts (-1: set aside)
+    struct RegionResult { std::vector<CompResult> comps; };
+    void process_region(const std::vector<int> &verts, RegionResult &out) {
+        std::vector<int> &order = comp_order_;
+        const int L = new_label();
+        for (int v : verts) set_lab(v, L);
+        for (int s : verts) {
+            if (lab(s) != L) continue;
+            bfs(s, L, order);
+            std::vector<int> comp(order);
+            for (int v : comp) dist[v] = -1;
+            const int Lc = new_label();
+            for (int v : comp) set_lab(v, Lc);
+            std::sort(comp.begin(), comp.end());
+            out.comps.emplace_back();
+            CompResult &cr = out.comps.back();
+            Split *best = (int)comp.size() <= leaf ? nullptr : best_split(comp, Lc);
+            if (!best) { cr.leaf = true; cr.verts = std::move(comp); }
+            else { cr.leaf = false; cr.verts = std::move(best->S); cr.P0 = std::move(best->P0); cr.P1 = std::move(best->P1); }
+        }
+    }
+    std::vector<int> comp_order_;
 };
 
 }  // namespace
@@ -383,29 +535,82 @@ void nested_dissection(int N, const std::vector<int> &adj_ptr, const std::vector
     // threads or on their timing (all ranks of a sharded run and every re-run build the identical plan).
     std::vector<Item> tasks;
     const size_t defer_below = N >= 1024 ? (size_t)N / 12 : 0;
-    {
+    int nthreads = 0;                                                     // 0: as many as the pool has
+    if (const char *e = getenv("APRILSAM_AMD_PLAN_THREADS")) nthreads = std::max(1, atoi(e));      // 1 = single-threaded planning
+    PlanPool *pool = (nthreads == 1 || N < 1024) ? nullptr : &PlanPool::get();
+    if (pool && pool->workers() == 0) pool = nullptr;
+    PlanPool::Session session(pool);
+    const bool prof = getenv("APRILSAM_AMD_PLAN_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = prof ? now() : 0;
+    if (!pool) {
         Dissector d(N, adj_ptr, adj, xy, leaf_nodes, tree, sh);
         d.run(std::move(top), defer_below, defer_below ? &tasks : nullptr);
+    } else {
+        // The same top of the tree, level by level: the regions of one level are independent -- few of them (the first levels):
+        // one after the other, each with its candidate splits side by side; several: side by side, one evaluator per thread.
+        // The tree nodes are created afterwards by replaying run()'s order over the results, so the numbering is the serial one.
+        using RR = Dissector::RegionResult;
+        std::vector<std::unique_ptr<RR>> results;
+        struct Pending { std::vector<int> verts; int res; };
+        std::vector<Pending> level, next;
+        results.emplace_back(new RR()); level.push_back({ std::move(top[0].verts), 0 });
+        const int nev = pool->workers() + 1;
+        std::vector<std::unique_ptr<Shared>> ev_sh(nev); std::vector<std::unique_ptr<Dissector>> ev(nev);
+        auto evaluator = [&](int who) -> Dissector & {            // (created by the thread that first needs it: its pages land near that thread)
+            if (!ev[who]) { ev_sh[who].reset(new Shared(N)); ev[who].reset(new Dissector(N, adj_ptr, adj, xy, leaf_nodes, tree, *ev_sh[who])); }
+            return *ev[who];
+        };
+        evaluator(0).pool = pool; evaluator(0).par_min = 1;
+        while (!level.empty()) {
+            if (level.size() < 3) for (Pending &pd : level) evaluator(0).process_region(pd.verts, *results[pd.res]);
+            else {
+                evaluator(0).pool = nullptr;            // (no job inside a job: the calling thread takes regions like everybody else)
+                pool->run((int)level.size(), [&](int i, int who) { evaluator(who).process_region(level[i].verts, *results[level[i].res]); });
+                evaluator(0).pool = pool;
+            }
+            next.clear();
+            for (Pending &pd : level)
+                for (Dissector::CompResult &cr : results[pd.res]->comps) {
+                    if (cr.leaf) continue;
+                    if (cr.P0.size() > defer_below) { cr.c0 = (int)results.size(); results.emplace_back(new RR()); next.push_back({ std::move(cr.P0), cr.c0 }); }
+                    if (cr.P1.size() > defer_below) { cr.c1 = (int)results.size(); results.emplace_back(new RR()); next.push_back({ std::move(cr.P1), cr.c1 }); }
+                }
+            level.swap(next);
+        }
+        // replay: run()'s stack discipline over the results
+        struct Ent { int res; std::vector<int> verts; int parent; };
+        std::vector<Ent> stack; stack.push_back({ 0, {}, -1 });
+        auto new_node = [&](std::vector<int> &&verts, int parent) {
+            const int id = (int)tree.nodes.size();
+            tree.nodes.emplace_back(); tree.nodes.back().verts = std::move(verts);
+            if (parent < 0) tree.roots.push_back(id); else tree.nodes[parent].children.push_back(id);
+            return id;
+        };
+        while (!stack.empty()) {
+            Ent e = std::move(stack.back()); stack.pop_back();
+            if (e.res < 0) { tasks.push_back({ std::move(e.verts), e.parent }); continue; }
+            for (Dissector::CompResult &cr : results[e.res]->comps) {
+                if (cr.leaf) { new_node(std::move(cr.verts), e.parent); continue; }
+                const int t = new_node(std::move(cr.verts), e.parent);
+                stack.push_back({ cr.c0, std::move(cr.P0), t });
+                stack.push_back({ cr.c1, std::move(cr.P1), t });
+            }
+        }
     }
+    const double t1 = prof ? now() : 0;
     if (tasks.empty()) return;
     const int nt = (int)tasks.size();
     std::vector<NDTree> sub(nt);
     auto work = [&](int i) {
         std::vector<Item> st; Item it; it.verts = std::move(tasks[i].verts); it.parent = -1; st.push_back(std::move(it));
-        Shared mine(N);           // private per-vertex state: sharing one set of arrays between threads is correct (disjoint
+        Shared mine(N);           // private labels and scratch: sharing one set of arrays between threads is correct (disjoint
         Dissector d(N, adj_ptr, adj, xy, leaf_nodes, sub[i], mine);      // vertices) but falsely shares cache lines -- measured: no speed-up
         d.run(std::move(st));
     };
-    unsigned hw = std::thread::hardware_concurrency();
-    int nthreads = std::max(1, std::min({ nt, 16, hw ? (int)hw : 1 }));
-    if (const char *e = getenv("APRILSAM_AMD_PLAN_THREADS")) nthreads = std::max(1, atoi(e));      // 1 = single-threaded planning
-    if (nthreads == 1) { for (int i = 0; i < nt; i++) work(i); }
-    else {
-        std::atomic<int> next{ 0 };
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; t++) pool.emplace_back([&] { for (int i; (i = next.fetch_add(1)) < nt;) work(i); });
-        for (auto &th : pool) th.join();
-    }
+    if (!pool) { for (int i = 0; i < nt; i++) work(i); }
+    else pool->run(nt, [&](int i, int) { work(i); });
+    if (prof) fprintf(stderr, "aprilsam_amd dissection N=%d: top of the tree %.3f ms, %d subtrees %.3f ms (%d worker threads)\n", N, t1 - t0, nt, now() - t1, pool ? pool->workers() : 0);
     for (int i = 0; i < nt; i++) {
         const int off = (int)tree.nodes.size(), parent = tasks[i].parent;
         for (NDTree::Node &nd : sub[i].nodes) { for (int &c : nd.children) c += off; tree.nodes.push_back(std::move(nd)); }

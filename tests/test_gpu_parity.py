@@ -280,6 +280,36 @@ def test_incremental_demo_matches_reference_schedule(lib, inc_fast):
     assert np.max(rel) < CHI2_RTOL, (int(np.argmax(rel)), float(np.max(rel)))
 
 
+@pytest.mark.parametrize("opts", [
+    {"inc_tail": 0},                                  # every step regenerates its fronts (one launch for the small ones)
+    {"inc_tail": 0, "inc_one": 0},                    # ... as prologue + multi-level fronts + multi-level back substitution
+    {"inc_multi": 0},                                 # ... one launch per level and direction (implies no k_inc_one / tail_refactor)
+    {"inc_inline": 0},                                # patches read across PCIe instead of from the kernel arguments
+    {"inc_one_spin": 0},                              # completion through hipStreamSynchronize
+    {"inc_one_threads": 1024}, {"inc_one_threads": 256},
+    {"inc_one_up": 1, "inc_one_dn": 1},               # k_inc_one for single-front steps only
+    {"tail_poses": 8},                                # short tail fronts: new tail fronts open often
+], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_incremental_step_launch_forms_agree_with_the_reference_golden(lib, opts):
+    """The launch forms of an incremental step (k_inc_one with tail_refactor, k_inc_one with regenerated fronts, multi-level
+    launches, per-level launches; inline / PCIe patches; completion word / stream synchronise) on the first 420 poses of the
+    demo: identical fall-back schedule, chi^2 within 1e-6 of the reference golden at every step."""
+    G = golden("m3500_inc_demo.npz")
+    n = 420
+    defaults = {"inc_tail": 1, "inc_one": 1, "inc_multi": 1, "inc_inline": 1, "inc_one_spin": 1, "inc_one_threads": 512,
+                "inc_one_up": 3, "inc_one_dn": 4, "tail_poses": 24}
+    for k, v in opts.items():
+        lib.set_option(k, v)
+    try:
+        res = harness.run_demo(lib, datasets.m3500_arrays(), max_poses=n, deterministic=True)
+    finally:
+        for k in opts:
+            lib.set_option(k, defaults[k])
+    assert np.array_equal(res["was_batch"], G["was_batch"][:n])
+    rel = np.abs(res["chi2"] - G["chi2"][:n]) / np.maximum(G["chi2"][:n], 1e-9)
+    assert np.max(rel) < CHI2_RTOL, (int(np.argmax(rel)), float(np.max(rel)))
+
+
 def test_incremental_general_usage_falls_back_to_replanning(lib, oracle):
     """factors between two OLD poses and steps without a new pose do not fit the frozen structure of the fast
     path: the library must notice and re-plan; results = exact solve of the incremental system on all poses

@@ -120,3 +120,38 @@ def test_pin_last_keeps_the_newest_poses_in_the_root_front(lib, oracle, pin):
     dx = solve(P, H, G, lam).reshape(N, 3)[P.pos]
     ref = oracle.solve_system(st, st, fa, fb, z, W, lam)
     assert np.max(np.abs(dx - ref)) < 1e-7 * max(1.0, np.max(np.abs(ref)))
+
+
+_PLAN_HASH_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from aprilsam_amd import datasets, host
+from tests.support.mf_emulator import PlanView
+lib = host.SolverLib()
+out = []
+cases = [datasets.m3500_batch(), lib.lattice_arrays(60), datasets.random_pose_graph(1500, 700, 5)]
+for s, fa, fb, z, W in cases:
+    P = PlanView(lib, len(s), fa, fb, xy=s[:, :2], leaf_nodes=16)
+    h = hashlib.sha256()
+    for name in ("perm", "front_first", "front_nsb", "front_parent", "front_rows", "lev_fronts"):
+        h.update(np.ascontiguousarray(getattr(P, name)).tobytes())
+    out.append(h.hexdigest()[:16])
+print(" ".join(out))
+"""
+
+
+def test_plan_does_not_depend_on_the_number_of_planner_threads():
+    """ordering.cpp: the top of the dissection tree is computed level by level on a pool of threads (regions side by side,
+    candidate splits side by side) and numbered afterwards in the serial order; the subtrees below are private per task.
+    The plan must be bit-identical for every thread count (all ranks of a sharded run build it independently).  One process
+    per count: the pool is sized when it is first used."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for nt in ("1", "2", "5", "16"):
+        env = dict(os.environ, APRILSAM_AMD_PLAN_THREADS=nt)
+        r = subprocess.run([sys.executable, "-c", _PLAN_HASH_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        seen[nt] = r.stdout.strip().splitlines()[-1]
+    assert len(set(seen.values())) == 1, seen
