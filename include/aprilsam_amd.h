@@ -267,6 +267,16 @@ void aprilsam_amd_clear_error(void);
  *   "inc_fast"          0 = every incremental step re-plans (default 1: frozen base plan + dirty root paths)
  *   "inc_multi"         0 = incremental steps launch their fronts / back substitution level by level (default 1: one multi-level
  *                       launch per direction, fronts synchronised by dependency flags)
+ *   "inc_one"           1 (default, needs inc_multi): an incremental step that regenerates at most "inc_one_up" (3) fronts and walks
+ *                       at most "inc_one_dn" (4) runs as ONE launch of one workgroup of "inc_one_threads" (512) threads -- patches,
+ *                       linearisation, fronts, back substitution, state update; "inc_one_spin" (1): its completion is a word in
+ *                       pinned host memory the host spins on (0: hipStreamSynchronize)
+ *   "inc_tail"          1 (default, needs inc_multi): steps whose new factors touch only the last 8 poses of the last tail front
+ *                       re-factorise that front's trailing columns alone (the front keeps the shape of a full one through phantom
+ *                       rows); 0 = every dirty front is re-assembled and re-factorised in full
+ *   "inc_inline"        1 (default): a small step's patches (<= 24 ranges, <= 2 KiB) travel in the kernel arguments; 0 = always read
+ *                       from pinned host memory by the kernel
+ *   "tail_poses"        own poses per tail front of the incremental path (default 24, at least 8)
  *   "persist"           1 (default): the top levels of the elimination tree -- as many as hold at most "persist_max_fronts"
  *                       (default 240) single-workgroup fronts -- run as ONE launch per sweep, fronts synchronised by
  *                       per-front dependency flags; 0 = one launch per level
