@@ -18,6 +18,7 @@ struct Options {
     int inc_one_up = 3, inc_one_dn = 4, inc_one_threads = 512, inc_one_spin = 1;
     int inc_tail = 1;             // ... and steps whose factors touch the last few poses of the last tail front alone re-factorise its trailing columns only
     int inc_inline = 1;           // ... a small step's table / factor / state patches travel in the kernel arguments instead of being read across PCIe
+    int speculate_factors = 1;    // warm batch calls: the pass over the factor objects (edits in place) runs under the GPU's work on the packed copies; an edit voids the run
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
     int small_threads = 1024;     // workgroup size of k_front_small (256 / 512 / 1024) on latency-bound levels ...
     int tp_threads = 512;         // ... and on throughput levels (>= tp_fronts fronts)
@@ -30,7 +31,7 @@ struct Options {
     int persist = 1;              // batch path: the top levels of the tree (few small fronts each) as ONE launch per sweep, fronts synchronised by dependency flags
     int persist_max_fronts = 240; // ... as many top levels as fit this many fronts
     int block_panels = 1;         // big fronts: the four panel steps of a 128-column outer block as two launches (diagonal block in LDS, row solves on the matrix cores)
-    int tail_poses = 24;          // incremental path: own poses per tail front (>= 8)
+    int tail_poses = 28;          // incremental path: own poses per tail front (>= 8; measured on the M3500 demo: 24 / 28 / 32 -> 546 / 530 / 528 ms total, median 0.038 / 0.0385 / 0.040 ms)
     int tile_assembly = 0;        // 1: big fronts assembled window by window in LDS and stored once (measured slower than the default: chunks of block columns, zero fill + L2 atomics)
     int blk_backsolve = 1;        // wide multi-workgroup fronts: back substitution 128 columns at a time by a chain workgroup + helpers (needs block_panels)
     int left_panels = 1;          // big fronts: panel steps apply the outer block's earlier panels themselves (no narrow update launches)

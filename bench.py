@@ -508,6 +508,11 @@ def main():
                    "batch_fallbacks": int(res["was_batch"].sum()) - 1,
                    "fallback_schedule_identical": bool(np.array_equal(res["was_batch"], G["was_batch"])),
                    "max_abs_state_err": float(np.max(np.abs(res["final_states"] - G["final_states"])))}
+            wb = res["was_batch"]; small = (~wb) & (ms <= 0.1)
+            inc["where_the_time_goes"] = {   # steps with a batch fall-back inside / steps that stay in the last tail front (one launch) / loop closures
+                "fallback_steps": int(wb.sum()), "fallback_ms": float(ms[wb].sum()),
+                "steps_up_to_0.1_ms": int(small.sum()), "their_ms": float(ms[small].sum()),
+                "steps_above_0.1_ms": int(((~wb) & ~small).sum()), "their_ms_": float(ms[(~wb) & ~small].sum())}
             if os.path.exists(REFLIB) and not a.no_cpu_baseline:
                 ref = host.SolverLib(REFLIB)
                 rr = harness.run_demo(ref, datasets.m3500_arrays(), deterministic=True)

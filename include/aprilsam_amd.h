@@ -218,7 +218,7 @@ typedef struct aprilsam_amd_stats {
     double ms_dev_linearize, ms_dev_factor, ms_dev_solve;   /* HIP-event timings inside ms_device */
     double chi2_before;                /* chi^2 at the linearisation point (from the linearise kernel) */
     int    error_code;                 /* 0, or the code of the failure that ended the last call on this param (see below) */
-    int    reserved1;
+    int    reserved1;          /* 1: a warm batch call launched on the packed factor copies, found an edited factor object afterwards and ran again (speculate_factors) */
 } aprilsam_amd_stats_t;
 int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_amd_stats_t *out);
 
@@ -264,6 +264,9 @@ void aprilsam_amd_clear_error(void);
  *                       or when the topology stops changing, a full re-plan follows.  0 = re-plan on every topology change
  *   "pin_last"          k > 0: the k newest poses are kept out of the nested dissection and form the root front ("recent
  *                       poses last", cf. aprilsam.c:1021-1098); default 0, measured effect in profiles/r02_inc_hist.json
+ *   "speculate_factors" 1 (default): a warm april_graph_cholesky call on an unchanged graph launches the step on the packed factor
+ *                       copies first and reads every factor object (z / W edited in place?) while the GPU works; an edit voids that
+ *                       run and the call starts over (stats.reserved1 = 1).  0 = read the factor objects before launching
  *   "inc_fast"          0 = every incremental step re-plans (default 1: frozen base plan + dirty root paths)
  *   "inc_multi"         0 = incremental steps launch their fronts / back substitution level by level (default 1: one multi-level
  *                       launch per direction, fronts synchronised by dependency flags)
@@ -276,7 +279,7 @@ void aprilsam_amd_clear_error(void);
  *                       rows); 0 = every dirty front is re-assembled and re-factorised in full
  *   "inc_inline"        1 (default): a small step's patches (<= 24 ranges, <= 2 KiB) travel in the kernel arguments; 0 = always read
  *                       from pinned host memory by the kernel
- *   "tail_poses"        own poses per tail front of the incremental path (default 24, at least 8)
+ *   "tail_poses"        own poses per tail front of the incremental path (default 28, at least 8)
  *   "persist"           1 (default): the top levels of the elimination tree -- as many as hold at most "persist_max_fronts"
  *                       (default 240) single-workgroup fronts -- run as ONE launch per sweep, fronts synchronised by
  *                       per-front dependency flags; 0 = one launch per level

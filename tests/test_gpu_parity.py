@@ -297,7 +297,7 @@ def test_incremental_step_launch_forms_agree_with_the_reference_golden(lib, opts
     G = golden("m3500_inc_demo.npz")
     n = 420
     defaults = {"inc_tail": 1, "inc_one": 1, "inc_multi": 1, "inc_inline": 1, "inc_one_spin": 1, "inc_one_threads": 512,
-                "inc_one_up": 3, "inc_one_dn": 4, "tail_poses": 24}
+                "inc_one_up": 3, "inc_one_dn": 4, "tail_poses": 28}
     for k, v in opts.items():
         lib.set_option(k, v)
     try:

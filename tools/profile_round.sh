@@ -34,7 +34,14 @@ timeout 120 python $ROOT/tools/chain_times.py 316 > $OUT/chain_times_lattice100k
 # the reference CPU on the 100k lattice on THIS host: one april_graph_cholesky call (about a minute, one core)
 timeout 400 python $ROOT/bench.py --steps 20 --warmup 3 --no-inc --no-cpu-baseline --lattice1m-k 0 --cpu-lattice100k > $OUT/bench_cpu_lattice100k.json 2> $OUT/bench_cpu_lattice100k.err
 # config 3: the incremental demo (first 1500 poses)
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_inc -- python $ROOT/tools/inc_demo.py 1500 > $OUT/stats_inc.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_inc -- python $ROOT/tools/inc_demo.py 3500 > $OUT/stats_inc.log 2>&1
+python $ROOT/tools/trace_medians.py $OUT/stats_inc > $OUT/inc_trace_medians.txt 2>&1
+# ... its host-side split and the phases inside k_inc_one (wall-clock stamps), where its time goes, the first call of a process, the planner
+APRILSAM_AMD_INC_PROFILE=2 timeout 100 python $ROOT/tools/inc_demo.py 3500 > $OUT/inc_profile.txt 2>&1
+timeout 100 python $ROOT/tools/inc_slowest.py > $OUT/inc_slowest.txt 2>&1
+timeout 100 python $ROOT/tools/first_call.py --count-first > $OUT/first_call.txt 2>&1
+APRILSAM_AMD_PLAN_PROFILE=1 timeout 100 python $ROOT/tools/plan_time.py > $OUT/plan_time.txt 2>&1
+timeout 60 $ROOT/tools/ubench/launch_lat > $OUT/ubench_launch_lat.txt 2>&1
 # instruction-rate micro-benchmarks the roofline discussion quotes
 timeout 60 $ROOT/tools/ubench/mfma_f64 > $OUT/ubench_mfma_f64.txt 2>&1
 timeout 60 $ROOT/tools/ubench/valu_lat > $OUT/ubench_valu_lat.txt 2>&1
