@@ -469,6 +469,41 @@ def test_factors_edited_in_place_are_seen_by_the_next_call(lib, reflib):
     assert abs(out[0][1][0] - out[0][0][0]) > 1e-3          # the edit did change chi^2
 
 
+def test_warm_call_speculates_on_unchanged_factors_and_starts_over_after_an_edit(lib, reflib):
+    """batch_impl: a warm call launches on the packed factor copies and reads the factor objects under the GPU's work
+    (option speculate_factors).  An unchanged graph takes that path (stats.reserved1 = 0, one run); an edit in place voids
+    the run and the call starts over (reserved1 = 1) -- and the states equal the reference's either way, with the option
+    off as well."""
+    arr = datasets.random_pose_graph(150, 110, 23)
+    res = {}
+    for name, L, spec in (("spec", lib, 1), ("nospec", lib, 0), ("ref", reflib, None)):
+        if spec is not None:
+            L.set_option("speculate_factors", spec)
+        try:
+            g = L.new_graph(); g.build_from_arrays(*arr); p = L.new_param()
+            tr, flags = [], []
+            for call in range(5):
+                if call == 2:
+                    g.factor(11).u.z[0] += 0.3                 # edited in place before the third call
+                if call == 4:
+                    g.factor(40).u.W.contents.data[4] *= 2.0   # ... and the information before the fifth
+                g.cholesky(p)
+                tr.append((g.chi2(), g.states()))
+                if spec is not None:
+                    flags.append(p.stats()["reserved1"])
+            res[name] = (tr, flags)
+            p.destroy(); g.destroy()
+        finally:
+            if spec is not None:
+                L.set_option("speculate_factors", 1)
+    assert res["spec"][1] == [0, 0, 1, 0, 1], res["spec"][1]      # cold, warm speculative, voided, speculative, voided
+    assert res["nospec"][1] == [0, 0, 0, 0, 0]
+    for name in ("spec", "nospec"):
+        for k, ((c1, s1), (c2, s2)) in enumerate(zip(res[name][0], res["ref"][0])):
+            assert abs(c1 - c2) <= 1e-9 * max(c2, 1.0), (name, k, c1, c2)
+            assert np.max(np.abs(s1 - s2)) < 1e-8, (name, k)
+
+
 def _growth_with_late_priors(lib, steps=60):
     """incremental growth where xytpos priors arrive in the middle of the run (the reference evaluates a prior at the
     node's STATE of that call, april_graph_xytpos.c:83-85, not at its l_point) and a batch fall-back happens later"""
