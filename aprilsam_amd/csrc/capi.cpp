@@ -150,10 +150,11 @@ long long aprilsam_amd_shard_plan(const aprilsam_amd_plan_t *plan, int world, in
 }
 
 long long aprilsam_amd_plan_query(const aprilsam_amd_plan_t *plan, const char *what, long long **out) {
+    std::string k(what);
+    if (k.compare(0, 3, "bd_") == 0 || k.compare(0, 3, "rd_") == 0) asam::build_gather_lists(const_cast<asam::Plan &>(plan->P));
     const asam::Plan &P = plan->P;
     std::vector<long long> v;
     auto from = [&](const auto &a) { v.assign(a.begin(), a.end()); };
-    std::string k(what);
     if (k == "perm") from(P.perm);
     else if (k == "pos") from(P.pos);
     else if (k == "front_first") from(P.f_first);

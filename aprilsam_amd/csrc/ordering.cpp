@@ -187,14 +187,15 @@ public:
         j.fn = nullptr;                        // (a worker arriving now finds next >= n and never calls it; fn is only read for an index < n)
     }
     // a plan in progress: wakes the workers once (without waiting for them) and keeps them polling until it is over
+    void begin_session() {
+        sessions.fetch_add(1, std::memory_order_seq_cst);
+        if (sleepers.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
+    }
+    void end_session() { sessions.fetch_sub(1, std::memory_order_seq_cst); }
     struct Session {
         PlanPool *p;
-        explicit Session(PlanPool *pool) : p(pool) {
-            if (!p) return;
-            p->sessions.fetch_add(1, std::memory_order_seq_cst);
-            if (p->sleepers.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(p->mu); p->cv.notify_all(); }
-        }
-        ~Session() { if (p) p->sessions.fetch_sub(1, std::memory_order_seq_cst); }
+        explicit Session(PlanPool *pool) : p(pool) { if (p) p->begin_session(); }
+        ~Session() { if (p) p->end_session(); }
     };
     static PlanPool &get() {
         static PlanPool *pool = [] {
@@ -520,6 +521,28 @@ struct Dissector {
 };
 
 }  // namespace
+
+static PlanPool *plan_pool_or_null() {
+    if (const char *e = getenv("APRILSAM_AMD_PLAN_THREADS")) if (atoi(e) <= 1) return nullptr;      // 1 = single-threaded planning
+    PlanPool &p = PlanPool::get();
+    return p.workers() > 0 ? &p : nullptr;
+}
+static thread_local int g_plan_sessions = 0;      // sessions opened by this thread (plan_parallel_for only fans out inside one)
+PlanSession::PlanSession(int n_nodes, int min_nodes) {
+    if (n_nodes < min_nodes) return;
+    PlanPool *p = plan_pool_or_null();
+    if (!p) return;
+    on = true; g_plan_sessions++;
+    p->begin_session();
+}
+PlanSession::~PlanSession() { if (on) { g_plan_sessions--; PlanPool::get().end_session(); } }
+void plan_parallel_for(int n, int grain, const std::function<void(int, int)> &body) {
+    if (n <= 0) return;
+    PlanPool *p = g_plan_sessions > 0 ? plan_pool_or_null() : nullptr;
+    const int chunks = p ? std::min((p->workers() + 1) * 4, std::max(1, n / std::max(1, grain))) : 1;
+    if (chunks <= 1) { body(0, n); return; }
+    p->run(chunks, [&](int i, int) { body((int)((long long)n * i / chunks), (int)((long long)n * (i + 1) / chunks)); });
+}
 
 void nested_dissection(int N, const std::vector<int> &adj_ptr, const std::vector<int> &adj,
                        const double *xy, int leaf_nodes, NDTree &tree) {

@@ -8,6 +8,7 @@
 // blocks (3 scalar unknowns each, aprilsam.c:141-148: idx = 3*position).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace asam {
@@ -79,6 +80,7 @@ struct Plan {
 // Build ordering + symbolic plan.  factor_nodes: 2 ints per factor (second = -1 for unary factors).
 // xy: optional 2 doubles per node (used only as a hint for geometric bisection; any values are valid).
 void build_plan(Plan &P, int N, int F, const int *factor_nodes, const double *xy, int leaf_nodes);
+void build_gather_lists(Plan &P);     // fills bd_* / rd_* (only the tests' host-side emulator reads them: derived on demand)
 
 // ---- pieces, exposed for tests --------------------------------------------------------------------------
 struct NDTree {
@@ -88,5 +90,12 @@ struct NDTree {
 };
 void nested_dissection(int N, const std::vector<int> &adj_ptr, const std::vector<int> &adj,
                        const double *xy, int leaf_nodes, NDTree &tree);
+
+// ---- the planner's thread pool (ordering.cpp), for the other phases of a plan ------------------------------
+// PlanSession: the pool's workers stay awake (polling) while one exists; for graphs below `min_nodes` nodes it does nothing and
+// plan_parallel_for runs on the calling thread.  plan_parallel_for: body(begin, end) over disjoint chunks of [0, n), each of
+// at least `grain` items; the chunks write disjoint outputs, so the result does not depend on the number of threads.
+struct PlanSession { explicit PlanSession(int n_nodes, int min_nodes = 1024); ~PlanSession(); PlanSession(const PlanSession &) = delete; bool on = false; };
+void plan_parallel_for(int n, int grain, const std::function<void(int, int)> &body);
 
 }  // namespace asam

@@ -11,6 +11,7 @@
 #include "errors.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
     auto stamp = [&] { if (prof && nph < 8) tph[nph++] = now(); };
     stamp();
 
+    PlanSession session(N);              // the planner's worker threads stay awake for the length of this plan (ordering.cpp)
     // ---- pose adjacency (deduplicated CSR) ------------------------------------------------------------
     std::vector<int> ap(N + 1, 0), ai;
     {
@@ -154,88 +156,78 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
     stamp();
     // ---- factor -> front assignment + deterministic gather lists -------------------------------------
     P.fac_front.assign(F, -1); P.fac_la.assign(F, -1); P.fac_lb.assign(F, -1); P.fac_swap.assign(F, 0);
-    struct Dest { int front, col, row, src; };
-    std::vector<Dest> bd, rd; bd.reserve((size_t)3 * F); rd.reserve((size_t)2 * F);
-    for (int f = 0; f < F; f++) {
-        int a = fn[2 * f], b = fn[2 * f + 1];
-        if (a < 0 || a >= N || b >= N || a == b) continue;          // malformed: ignored
-        int pa = P.pos[a], pb = b >= 0 ? P.pos[b] : -1;
-        int t = pos_front[(pb >= 0 && pb < pa) ? pb : pa];
-        int la = local_index(t, pa), lb = pb >= 0 ? local_index(t, pb) : -1;
-        if (la < 0 || (pb >= 0 && lb < 0)) fail(ERR_INTERNAL, "factor %d not inside its front", f);
-        P.fac_front[f] = t; P.fac_la[f] = la; P.fac_lb[f] = lb;
-        bd.push_back({ t, la, la, 3 * f + 0 });
-        rd.push_back({ t, la, 0, 2 * f + 0 });
-        if (lb >= 0) {
-            P.fac_swap[f] = la < lb;
-            bd.push_back({ t, std::min(la, lb), std::max(la, lb), 3 * f + 1 });
-            bd.push_back({ t, lb, lb, 3 * f + 2 });
-            rd.push_back({ t, lb, 0, 2 * f + 1 });
+    std::atomic<int> lost{ -1 };
+    plan_parallel_for(F, 4096, [&](int f0, int f1) {               // the searches, side by side ...
+        for (int f = f0; f < f1; f++) {
+            int a = fn[2 * f], b = fn[2 * f + 1];
+            if (a < 0 || a >= N || b >= N || a == b) continue;          // malformed: ignored
+            int pa = P.pos[a], pb = b >= 0 ? P.pos[b] : -1;
+            int t = pos_front[(pb >= 0 && pb < pa) ? pb : pa];
+            int la = local_index(t, pa), lb = pb >= 0 ? local_index(t, pb) : -1;
+            if (la < 0 || (pb >= 0 && lb < 0)) { lost.store(f); continue; }
+            P.fac_front[f] = t; P.fac_la[f] = la; P.fac_lb[f] = lb;
         }
-    }
-    // order (front, col, row, src): counting sort by front, then a sort of 64-bit packed keys inside every (small) bucket --
-    // several times faster than one comparison sort over all 5 F records, and planning sits on the cold-call path
-    auto sort_dests = [&](std::vector<Dest> &v) {
-        std::vector<int> ptr(nT + 1, 0);
-        for (const Dest &d : v) ptr[d.front + 1]++;
-        for (int t = 0; t < nT; t++) ptr[t + 1] += ptr[t];
-        std::vector<unsigned long long> key(v.size());
-        { std::vector<int> fill(ptr.begin(), ptr.end() - 1);
-          for (const Dest &d : v) key[fill[d.front]++] = ((unsigned long long)(unsigned)d.col << 44) | ((unsigned long long)(unsigned)(d.row + 1) << 26) | (unsigned)d.src; }
-        for (int t = 0; t < nT; t++) {
-            std::sort(key.begin() + ptr[t], key.begin() + ptr[t + 1]);
-            for (int i = ptr[t]; i < ptr[t + 1]; i++) v[i] = { t, (int)(key[i] >> 44), (int)((key[i] >> 26) & 0x3ffff) - 1, (int)(key[i] & 0x3ffffff) };
-        }
-    };
-    static_assert(sizeof(unsigned long long) == 8, "packed sort keys");
+    });
+    if (lost.load() >= 0) fail(ERR_INTERNAL, "factor %d not inside its front", lost.load());
+    for (int f = 0; f < F; f++) if (P.fac_front[f] >= 0 && P.fac_lb[f] >= 0) P.fac_swap[f] = P.fac_la[f] < P.fac_lb[f];
     if ((size_t)3 * F >= (1u << 26)) fail(ERR_UNSUPPORTED, "%d factors: this build handles up to %u (packed sort keys of the symbolic analysis)", F, (1u << 26) / 3 - 1);
-    sort_dests(bd);
-    sort_dests(rd);
-    auto compress = [&](const std::vector<Dest> &v, std::vector<int> &front_ptr, std::vector<int> &row, std::vector<int> &col,
-                        std::vector<int> &src_ptr, std::vector<int> &src) {
-        front_ptr.assign(nT + 1, 0); row.clear(); col.clear(); src_ptr.clear(); src.clear();
-        src_ptr.push_back(0);
-        for (size_t i = 0; i < v.size(); i++) {
-            bool fresh = i == 0 || v[i].front != v[i - 1].front || v[i].col != v[i - 1].col || v[i].row != v[i - 1].row;
-            if (fresh) { if (i) src_ptr.push_back((int)src.size()); row.push_back(v[i].row); col.push_back(v[i].col); front_ptr[v[i].front + 1]++; }
-            src.push_back(v[i].src);
-        }
-        if (!v.empty()) src_ptr.push_back((int)src.size());
-        for (int t = 0; t < nT; t++) front_ptr[t + 1] += front_ptr[t];
-    };
-    std::vector<int> dummy_row;
-    compress(bd, P.bd_front_ptr, P.bd_row, P.bd_col, P.bd_src_ptr, P.bd_src);
-    compress(rd, P.rd_front_ptr, dummy_row, P.rd_col, P.rd_src_ptr, P.rd_src);
+    static_assert(sizeof(unsigned long long) == 8, "packed sort keys");
+    P.bd_front_ptr.clear(); P.rd_front_ptr.clear();       // (the per-kind gather lists are derived on demand: build_gather_lists)
 
     stamp();
     // ---- unified destination records + contribution slots (device layout) --------------------------------
     {
-        struct U { int front, col, row, src, rhs; };
-        std::vector<U> all; all.reserve(bd.size() + rd.size());
-        for (const Dest &d : bd) all.push_back({ d.front, d.col, d.row, d.src, 0 });
-        for (const Dest &d : rd) all.push_back({ d.front, d.col, -1, d.src, 1 });     // brow -1 = the rhs row
-        {   // same order as above with brow = -1 first inside a column: merge of two sorted runs per front = one sort of packed keys per bucket
-            std::vector<int> ptr(nT + 1, 0);
-            for (const U &u : all) ptr[u.front + 1]++;
-            for (int t = 0; t < nT; t++) ptr[t + 1] += ptr[t];
-            std::vector<unsigned long long> key(all.size());
-            { std::vector<int> fill(ptr.begin(), ptr.end() - 1);
-              for (const U &u : all) key[fill[u.front]++] = ((unsigned long long)(unsigned)u.col << 45) | ((unsigned long long)(unsigned)(u.row + 1) << 27) | ((unsigned long long)(unsigned)u.src << 1) | (unsigned)u.rhs; }
-            for (int t = 0; t < nT; t++) {
-                std::sort(key.begin() + ptr[t], key.begin() + ptr[t + 1]);
-                for (int i = ptr[t]; i < ptr[t + 1]; i++) all[i] = { t, (int)(key[i] >> 45), (int)((key[i] >> 27) & 0x3ffff) - 1, (int)((key[i] >> 1) & 0x3ffffff), (int)(key[i] & 1) };
+        // One record per destination block (brow -1 = the rhs row) with the consecutive slots of its contributions.  Order inside a
+        // front: (col, row with the rhs row first, contribution id) -- a counting sort by front, then a sort of 64-bit packed keys
+        // inside every (small) bucket, the buckets side by side: several times faster than one comparison sort over all 5 F
+        // entries, and planning sits on the cold-call path.
+        std::vector<int> ptr(nT + 1, 0);
+        for (int f = 0; f < F; f++) if (P.fac_front[f] >= 0) ptr[P.fac_front[f] + 1] += P.fac_lb[f] >= 0 ? 5 : 2;
+        for (int t = 0; t < nT; t++) ptr[t + 1] += ptr[t];
+        const size_t total = (size_t)ptr[nT];
+        std::vector<unsigned long long> key(total);
+        auto pack = [](int col, int row, int src, int rhs) {
+            return ((unsigned long long)(unsigned)col << 45) | ((unsigned long long)(unsigned)(row + 1) << 27) | ((unsigned long long)(unsigned)src << 1) | (unsigned)rhs;
+        };
+        {
+            std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+            for (int f = 0; f < F; f++) {
+                const int t = P.fac_front[f], la = P.fac_la[f], lb = P.fac_lb[f];
+                if (t < 0) continue;
+                int &w = fill[t];
+                key[w++] = pack(la, la, 3 * f + 0, 0); key[w++] = pack(la, -1, 2 * f + 0, 1);
+                if (lb >= 0) {
+                    key[w++] = pack(std::min(la, lb), std::max(la, lb), 3 * f + 1, 0);
+                    key[w++] = pack(lb, lb, 3 * f + 2, 0); key[w++] = pack(lb, -1, 2 * f + 1, 1);
+                }
             }
         }
-        P.dest_front_ptr.assign(nT + 1, 0); P.dest.clear();
-        P.slot_blk.assign((size_t)3 * F, -1); P.slot_rhs.assign((size_t)2 * F, -1);
-        for (size_t i = 0; i < all.size(); i++) {
-            const bool fresh = i == 0 || all[i].front != all[i - 1].front || all[i].col != all[i - 1].col || all[i].row != all[i - 1].row;
-            if (fresh) { P.dest.push_back({ all[i].row, all[i].col, (int)i, (int)i }); P.dest_front_ptr[all[i].front + 1]++; }
-            P.dest.back().src_end = (int)i + 1;
-            (all[i].rhs ? P.slot_rhs : P.slot_blk)[all[i].src] = (int)i;
-        }
+        auto same_dest = [](unsigned long long a, unsigned long long b) { return (a >> 27) == (b >> 27); };     // same (col, row)
+        P.dest_front_ptr.assign(nT + 1, 0);
+        plan_parallel_for(nT, 64, [&](int t0, int t1) {
+            for (int t = t0; t < t1; t++) {
+                std::sort(key.begin() + ptr[t], key.begin() + ptr[t + 1]);
+                int fresh = 0;
+                for (int i = ptr[t]; i < ptr[t + 1]; i++) fresh += i == ptr[t] || !same_dest(key[i], key[i - 1]);
+                P.dest_front_ptr[t + 1] = fresh;
+            }
+        });
         for (int t = 0; t < nT; t++) P.dest_front_ptr[t + 1] += P.dest_front_ptr[t];
-        P.n_slots = (int)all.size();
+        P.dest.resize((size_t)P.dest_front_ptr[nT]);
+        P.slot_blk.assign((size_t)3 * F, -1); P.slot_rhs.assign((size_t)2 * F, -1);
+        plan_parallel_for(nT, 64, [&](int t0, int t1) {
+            for (int t = t0; t < t1; t++) {
+                int d = P.dest_front_ptr[t] - 1;
+                for (int i = ptr[t]; i < ptr[t + 1]; i++) {
+                    const unsigned long long k = key[i];
+                    const int col = (int)(k >> 45), row = (int)((k >> 27) & 0x3ffff) - 1, src = (int)((k >> 1) & 0x3ffffff), rhs = (int)(k & 1);
+                    if (i == ptr[t] || !same_dest(k, key[i - 1])) P.dest[++d] = { row, col, i, i };
+                    P.dest[d].src_end = i + 1;
+                    (rhs ? P.slot_rhs : P.slot_blk)[src] = i;
+                }
+            }
+        });
+        P.n_slots = (int)total;
     }
 
     stamp();
@@ -257,6 +249,56 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
     if (prof && nph == 8)
         fprintf(stderr, "aprilsam_amd planner N=%d F=%d: adjacency %.3f dissection %.3f front structure %.3f levels %.3f factor lists %.3f records+slots %.3f offsets %.3f | total %.3f ms\n",
                 N, F, tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2], tph[4] - tph[3], tph[5] - tph[4], tph[6] - tph[5], tph[7] - tph[6], tph[7] - tph[0]);
+}
+
+// The per-kind gather lists (block destinations / rhs destinations with their contributing factors in a fixed order): a
+// restatement of the destination records for the host-side emulator of the tests (aprilsam_amd_plan_query "bd_*" / "rd_*");
+// the device never reads them, so they are derived on demand.
+void build_gather_lists(Plan &P) {
+    if (!P.bd_front_ptr.empty()) return;
+    const int F = P.F, nT = P.nF;
+    struct Dest { int front, col, row, src; };
+    std::vector<Dest> bd, rd; bd.reserve((size_t)3 * F); rd.reserve((size_t)2 * F);
+    for (int f = 0; f < F; f++) {
+        const int t = P.fac_front[f], la = P.fac_la[f], lb = P.fac_lb[f];
+        if (t < 0) continue;
+        bd.push_back({ t, la, la, 3 * f + 0 });
+        rd.push_back({ t, la, 0, 2 * f + 0 });
+        if (lb >= 0) {
+            bd.push_back({ t, std::min(la, lb), std::max(la, lb), 3 * f + 1 });
+            bd.push_back({ t, lb, lb, 3 * f + 2 });
+            rd.push_back({ t, lb, 0, 2 * f + 1 });
+        }
+    }
+    auto sort_dests = [&](std::vector<Dest> &v) {
+        std::vector<int> ptr(nT + 1, 0);
+        for (const Dest &d : v) ptr[d.front + 1]++;
+        for (int t = 0; t < nT; t++) ptr[t + 1] += ptr[t];
+        std::vector<unsigned long long> key(v.size());
+        { std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+          for (const Dest &d : v) key[fill[d.front]++] = ((unsigned long long)(unsigned)d.col << 44) | ((unsigned long long)(unsigned)(d.row + 1) << 26) | (unsigned)d.src; }
+        for (int t = 0; t < nT; t++) {
+            std::sort(key.begin() + ptr[t], key.begin() + ptr[t + 1]);
+            for (int i = ptr[t]; i < ptr[t + 1]; i++) v[i] = { t, (int)(key[i] >> 44), (int)((key[i] >> 26) & 0x3ffff) - 1, (int)(key[i] & 0x3ffffff) };
+        }
+    };
+    sort_dests(bd);
+    sort_dests(rd);
+    auto compress = [&](const std::vector<Dest> &v, std::vector<int> &front_ptr, std::vector<int> &row, std::vector<int> &col,
+                        std::vector<int> &src_ptr, std::vector<int> &src) {
+        front_ptr.assign(nT + 1, 0); row.clear(); col.clear(); src_ptr.clear(); src.clear();
+        src_ptr.push_back(0);
+        for (size_t i = 0; i < v.size(); i++) {
+            bool fresh = i == 0 || v[i].front != v[i - 1].front || v[i].col != v[i - 1].col || v[i].row != v[i - 1].row;
+            if (fresh) { if (i) src_ptr.push_back((int)src.size()); row.push_back(v[i].row); col.push_back(v[i].col); front_ptr[v[i].front + 1]++; }
+            src.push_back(v[i].src);
+        }
+        if (!v.empty()) src_ptr.push_back((int)src.size());
+        for (int t = 0; t < nT; t++) front_ptr[t + 1] += front_ptr[t];
+    };
+    std::vector<int> dummy_row;
+    compress(bd, P.bd_front_ptr, P.bd_row, P.bd_col, P.bd_src_ptr, P.bd_src);
+    compress(rd, P.rd_front_ptr, dummy_row, P.rd_col, P.rd_src_ptr, P.rd_src);
 }
 
 }  // namespace asam
