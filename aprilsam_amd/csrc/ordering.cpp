@@ -11,6 +11,7 @@
 // separator through Koenig's theorem (Hopcroft-Karp matching on the cut's bipartite graph); the better
 // one wins.  Regions of <= leaf_nodes poses become dense leaves.
 #include "plan.h"
+#include "errors.h"
 
 #include <algorithm>
 #include <atomic>
@@ -132,7 +133,7 @@ class PlanPool {
     // from worker to worker costs a futex wake per hand-over, which on a virtual machine is longer than the jobs -- so a
     // slot is guarded Dekker-style: a worker announces "inside job g" (state) and then checks the slot's tag; the caller
     // closes the slot (tag = -1), then waits for every "inside" announcement of its previous use to be withdrawn, then refills it.
-    struct alignas(128) Job { std::function<void(int, int)> fn; int n = 0; std::atomic<int> next{ 0 }, done{ 0 }; std::atomic<long long> tag{ -1 }; };
+    struct alignas(128) Job { std::function<void(int, int)> fn; int n = 0; std::atomic<int> next{ 0 }, done{ 0 }, failed{ 0 }; std::atomic<long long> tag{ -1 }; };
     struct alignas(128) WState { std::atomic<long long> v{ 0 }; };      // 2 g + 1: inside job g; even: not inside any
     Job slot[2];
     std::unique_ptr<WState[]> state;
@@ -141,7 +142,9 @@ class PlanPool {
     std::atomic<int> sessions{ 0 };            // plans in progress: their jobs follow each other within microseconds, workers stay awake
     std::mutex one_caller;                     // (plans of different params may be built on different application threads)
     int nworkers = 0;
-    static void drain(Job &j, int who) { for (int i; (i = j.next.fetch_add(1, std::memory_order_acq_rel)) < j.n;) { j.fn(i, who); j.done.fetch_add(1, std::memory_order_acq_rel); } }
+    static void drain(Job &j, int who) { for (int i; (i = j.next.fetch_add(1, std::memory_order_acq_rel)) < j.n;) {
+        try { j.fn(i, who); } catch (...) { j.failed.store(1, std::memory_order_release); }      // (an exception must not leave a worker thread: reported by the caller)
+        j.done.fetch_add(1, std::memory_order_acq_rel); } }
     void worker(int w) {
         long long seen = 0;
         for (;;) {
@@ -178,13 +181,14 @@ public:
         Job &j = slot[g & 1];
         j.tag.store(-1, std::memory_order_seq_cst);                              // closed: nobody new gets in ...
         for (int w = 0; w < nworkers; w++) while (state[w].v.load(std::memory_order_seq_cst) == 2 * (g - 2) + 1) cpu_relax();     // ... and its last users are out
-        j.fn = f; j.n = cnt; j.next.store(0, std::memory_order_relaxed); j.done.store(0, std::memory_order_relaxed);
+        j.fn = f; j.n = cnt; j.next.store(0, std::memory_order_relaxed); j.done.store(0, std::memory_order_relaxed); j.failed.store(0, std::memory_order_relaxed);
         j.tag.store(g, std::memory_order_seq_cst);
         gen.store(g, std::memory_order_seq_cst);
         if (sleepers.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
         drain(j, 0);
         while (j.done.load(std::memory_order_acquire) < cnt) cpu_relax();
         j.fn = nullptr;                        // (a worker arriving now finds next >= n and never calls it; fn is only read for an index < n)
+        if (j.failed.load(std::memory_order_acquire)) fail(ERR_OOM, "a planner task failed (out of host memory?)");
     }
     // a plan in progress: wakes the workers once (without waiting for them) and keeps them polling until it is over
     void begin_session() {
