@@ -193,6 +193,7 @@ struct PatchList {
 struct GraphPack {
     int N = 0, F = 0;                  // packed counts
     std::vector<const void *> fptr;    // factor object pointers already packed (cache validation)
+    std::vector<int> pending;          // poses whose pinned state mirror is ahead of the device copy (written by apply_visits)
     HBuf<int> h_fa, h_fb;
     HBuf<double> h_z, h_W, h_state, h_lp, h_dx;
     DBuf<int> d_fa, d_fb;
@@ -426,6 +427,13 @@ static bool pack_states_diff(GraphPack &gp, const april_graph_t *g) {
         }
     }
     gp.N = N;
+    // poses the previous step updated itself (apply_visits brought their mirrors up to date: the walk above found them equal):
+    // the device copy of their state is what is stale
+    if (!full) {
+        if (gp.pending.size() > 48) full = true;
+        else for (int i : gp.pending) if (i < N && std::find(gp.changed.begin(), gp.changed.end(), i) == gp.changed.end()) gp.changed.push_back(i);
+    }
+    gp.pending.clear();
     if (gp.changed.size() > 48) full = true;
     return !full;
 }
@@ -660,6 +668,7 @@ constexpr long long INC_POOL_MIN = 8ll << 20;             // doubles (64 MB; the
 static int waves_of(int nt) { return nt >= 1024 ? 16 : (nt >= 512 ? 8 : 4); }
 // workgroup size of k_front_small on a level with n fronts: latency levels take the big workgroup (more lanes on one
 // front's critical path), throughput levels the smaller one (more workgroups per CU)
+static double g_incsub[8] = { 0 }; static long long g_incsub_n = 0;      // APRILSAM_AMD_INC_PROFILE: host sub-phases of the general incremental path (ms, summed)
 static const bool g_incprof_stamps = [] { const char *e = getenv("APRILSAM_AMD_INC_PROFILE"); return e && *e == '2'; }();      // (see IncProf)
 static int small_threads_for(size_t n_fronts) { return (int)n_fronts >= g_opt.tp_fronts ? std::min(g_opt.small_threads, g_opt.tp_threads) : g_opt.small_threads; }
 
@@ -1361,6 +1370,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     }
     // ... and when the reference's walk stays on a short root path, the whole step is decided here, without the general
     // machinery below (whose cost grows with the number of fronts and levels): one k_inc_one launch
+    g_incsub[6] += tail_fast ? 1 : 0; g_incsub[7] += (tail_fast && needed && patch_states) ? 1 : 0;
     if (tail_fast && needed && g_opt.inc_one && g_opt.wave_backsolve && patch_states && F <= gp.F_cap) {
         const int T = tstep.t, first = I.t_first.back(), nT0 = (int)I.t_first.size(), nFr0 = nF0 + nT0;
         const int n_new = I.t_cnt.back() + (N - std::max(Nold, Nb)), nph = TAIL_POSES - n_new;
@@ -1505,6 +1515,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             t = I.parent[t];
         }
     };
+    const double tsub0 = now_ms();
     // ---- 1. owners of the new factors, tail rows along root paths ----------------------------------------------
     for (int f = Fold; f < F; f++) {
         const int a = fa[f], b = fb[f];
@@ -1526,6 +1537,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         I.dirty[owner] = 1;
     }
     for (int t = 0; t < nFr; t++) if (I.dirty[t] && I.parent[t] >= 0) I.dirty[I.parent[t]] = 1;     // (parents have larger ids)
+    const double tsub1 = now_ms();
     // ---- 2. regenerate dirty fronts (children before parents) ----------------------------------------------------
     std::vector<int> &st_i32 = I.st_i32; std::vector<DestRec> &st_dest = I.st_dest; std::vector<ChildRec> &st_child = I.st_child;
     st_i32.clear(); st_dest.clear(); st_child.clear();
@@ -1645,6 +1657,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     if (I.i32_used + (long long)st_i32.size() > (long long)c.d_i32.cap || I.dest_used + (long long)st_dest.size() > (long long)c.d_dest.cap ||
         I.child_used + (long long)st_child.size() > (long long)c.d_child.cap || (size_t)9 * I.slots_used > c.d_H.cap || (size_t)nFr > c.d_fd.cap ||
         (size_t)N > c.d_perm.cap) return false;
+    const double tsub2 = now_ms();
     // ---- 3. launch tables of the dirty fronts (transient region behind the base tables) + back-substitution lists -----
     std::vector<int> &tab = I.st_tab; tab.clear(); std::vector<LevelPlan> dl(nLev);
     auto dims = [&](int t, int *nsb, int *nub) { *nsb = nsb_of(t); *nub = I.cur_nub[t]; };
@@ -1787,6 +1800,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     if (tail_fast && !one && tail_refactor_lds() > 64 * 1024) return false;       // (never: the refactorisation alone runs as k_inc_one without lists)
     if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return false;
     c.st.reserved0 = (int)fd_dirty.size();              // fronts regenerated by this step (tools/inc_hist.py)
+    const double tsub3 = now_ms();
     // ---- 4. uploads: every table update of this step, the new factors and the new states through ONE pinned staging
     //         buffer, scattered by one kernel (k_apply_patches) -- no copy-engine call on the path ---------------------------
     PatchList &PL = c.patches;
@@ -1833,6 +1847,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         for (int i = 0; i < nT; i++) I.st_ids[i] = I.nLev0 + i;
         PL.add(c.d_flevel.p + nF0, I.st_ids.data(), (size_t)nT * 4);
     }
+    const double tsub4 = now_ms();
     // ---- 5. numeric: new factors linearised, dirty fronts level by level, back substitution, update ----------------------
     set_small_attr();
     if (batch) {
@@ -1950,6 +1965,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     }
     gp.new_states = gp.h_out.p;
     HIPCHECK(hipGetLastError());
+    if (!batch) { const double te = now_ms(); g_incsub[0] += tsub1 - tsub0; g_incsub[1] += tsub2 - tsub1; g_incsub[2] += tsub3 - tsub2; g_incsub[3] += tsub4 - tsub3; g_incsub[4] += te - tsub4; g_incsub[5] += (double)fd_dirty.size(); g_incsub_n++; }
     if (nT > 0 && I.dirty[nFr - 1]) I.tail_ok = g_opt.inc_tail ? nFr - 1 : -1;      // (re)generated or refactorised by this step, in the padded layout
     for (int t : fd_dirty) I.dirty[t] = 0;
     // the pattern folded into the device structures (a later batch call compares against it)
@@ -2165,6 +2181,8 @@ struct IncProf {
         }
         fprintf(stderr, "aprilsam_amd inc profile, MEDIANS (ms): pack %.4f model %.4f upload %.4f plan+enqueue %.4f d2h+sync %.4f writeback %.4f | total %.4f\n",
                 med[0], med[1], med[2], med[3], med[4], med[5], med[6]);
+        if (g_incsub_n) fprintf(stderr, "aprilsam_amd inc profile, general path over %lld steps (us/step): owners %.2f regenerate fronts %.2f launch tables %.2f patches %.2f enqueue %.2f | fronts regenerated per step %.1f | steps eligible for tail_refactor %.0f, of them with a short walk and patched states %.0f\n",
+                                g_incsub_n, 1e3 * g_incsub[0] / g_incsub_n, 1e3 * g_incsub[1] / g_incsub_n, 1e3 * g_incsub[2] / g_incsub_n, 1e3 * g_incsub[3] / g_incsub_n, 1e3 * g_incsub[4] / g_incsub_n, g_incsub[5] / g_incsub_n, g_incsub[6], g_incsub[7]);
         if (!kst.empty()) {
             double km[4];
             for (int k = 0; k < 4; k++) {
@@ -2371,6 +2389,12 @@ static void apply_visits(Context &c, GraphPack &gp, april_graph_t *g, april_grap
         if (!update) continue;
         if (std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2])) continue;   // april_graph_xyt.c:304-305
         memcpy(nd->state, gp.new_states + (size_t)3 * n, 24);             // l_point + dx, theta wrapped (state update on the device)
+        // the pinned mirror follows right here (the next call's walk over the node objects then finds this pose unchanged instead
+        // of copying it again -- after a full walk that is every pose); the device copy is brought up to date by that call
+        // (a pose whose new state equals the old one bit for bit -- most of a full walk: the far past does not move -- needs nothing)
+        if (gp.mirror_sync && gp.new_states != gp.h_state.p && memcmp(gp.h_state.p + (size_t)3 * n, gp.new_states + (size_t)3 * n, 24) != 0) {
+            memcpy(gp.h_state.p + (size_t)3 * n, gp.new_states + (size_t)3 * n, 24); gp.pending.push_back(n);
+        }
     }
     if (param->delta_x) {
         free(param->delta_x);
