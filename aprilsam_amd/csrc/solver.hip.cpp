@@ -1356,7 +1356,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     // The commonest step -- new poses and factors among the last few poses of the LAST tail front -- re-factorises that front's
     // trailing columns only (tail_refactor, kernels.hip.h): the front's factor on the device must be complete, its array
     // keeps its shape (phantom rows, below), and nothing else may be touched by the step's factors.
-    bool tail_fast = false; TailStep tstep{ -1, 0, 0 };
+    bool tail_fast = false; TailStep tstep{ -1, 0, 0, 0, 0, 0, 0 };
     if (!batch && g_opt.inc_tail && g_opt.inc_multi && g_opt.persist && !I.t_first.empty() && I.tail_ok == nF0 + (int)I.t_first.size() - 1 && F > Fold) {
         const int first = I.t_first.back(), n_old = I.t_cnt.back(), n_new = n_old + (N - std::max(Nold, Nb));
         int lo = first + n_old;                        // (poses added by this step: all of their columns are new)
@@ -1366,7 +1366,10 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             ok = a >= first && (b < 0 || b >= first);
             lo = std::min(lo, b >= 0 ? std::min(a, b) : a);
         }
-        if (ok && n_new - (lo - first) <= TAILK) { tail_fast = true; tstep = TailStep{ nF0 + (int)I.t_first.size() - 1, lo - first, n_old }; }
+        if (ok && n_new - (lo - first) <= TAILK) {
+            const FrontDesc &Dt = I.fd[nF0 + (int)I.t_first.size() - 1];      // (its shape stays: nsb + nub = the padded capacity)
+            tail_fast = true; tstep = TailStep{ nF0 + (int)I.t_first.size() - 1, lo - first, n_old, n_new, Dt.nsb + Dt.nub, first, Dt.off };
+        }
     }
     // ... and when the reference's walk stays on a short root path, the whole step is decided here, without the general
     // machinery below (whose cost grows with the number of fronts and levels): one k_inc_one launch
