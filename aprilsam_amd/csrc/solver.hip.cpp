@@ -398,6 +398,7 @@ static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp, boo
         if (with_lp) memcpy(gp.h_lp.p + (size_t)3 * i, n->l_point, 24);
     }
     gp.N = N;
+    gp.pending.clear();           // (every state goes to the device below, or through k_load_states: nothing is left behind the mirrors)
     gp.d_state.need((size_t)3 * N); gp.d_lp.need((size_t)3 * N); gp.d_dx.need((size_t)3 * N);
     if (!upload) return;          // (the batch step reads the pinned mirror from its first kernel, k_load_states)
     HIPCHECK(hipMemcpyAsync(gp.d_state.p, gp.h_state.p, (size_t)24 * N, hipMemcpyHostToDevice, gp.stream));
@@ -408,6 +409,7 @@ static void pack_states(GraphPack &gp, const april_graph_t *g, bool with_lp, boo
 // (gp.changed) -- typically the new pose, the poses the previous step updated, whatever the caller moved.  Returns true when
 // patching the listed poses brings the device arrays up to date; false when a full load is needed (mirrors and device not
 // known to agree, a buffer had to grow, or too many poses changed for patches to pay).
+static long long g_full_reason[4] = { 0 };      // APRILSAM_AMD_INC_PROFILE: why a step loaded every state (mirrors not in step / own updates / caller's changes), steps
 static bool pack_states_diff(GraphPack &gp, const april_graph_t *g) {
     const int N = zsize(g->nodes);
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
@@ -429,12 +431,14 @@ static bool pack_states_diff(GraphPack &gp, const april_graph_t *g) {
     gp.N = N;
     // poses the previous step updated itself (apply_visits brought their mirrors up to date: the walk above found them equal):
     // the device copy of their state is what is stale
+    g_full_reason[3]++;
+    if (full) g_full_reason[0]++;
     if (!full) {
-        if (gp.pending.size() > 48) full = true;
+        if (gp.pending.size() > 48) { full = true; g_full_reason[1]++; }
         else for (int i : gp.pending) if (i < N && std::find(gp.changed.begin(), gp.changed.end(), i) == gp.changed.end()) gp.changed.push_back(i);
     }
     gp.pending.clear();
-    if (gp.changed.size() > 48) full = true;
+    if (!full && gp.changed.size() > 48) { full = true; g_full_reason[2]++; }
     return !full;
 }
 
@@ -2184,6 +2188,8 @@ struct IncProf {
         }
         fprintf(stderr, "aprilsam_amd inc profile, MEDIANS (ms): pack %.4f model %.4f upload %.4f plan+enqueue %.4f d2h+sync %.4f writeback %.4f | total %.4f\n",
                 med[0], med[1], med[2], med[3], med[4], med[5], med[6]);
+        fprintf(stderr, "aprilsam_amd inc profile, states: %lld steps; all states loaded because the mirrors were not in step %lld, the library's own updates > 48 poses %lld, the caller's changes > 48 poses %lld\n",
+                g_full_reason[3], g_full_reason[0], g_full_reason[1], g_full_reason[2]);
         if (g_incsub_n) fprintf(stderr, "aprilsam_amd inc profile, general path over %lld steps (us/step): owners %.2f regenerate fronts %.2f launch tables %.2f patches %.2f enqueue %.2f | fronts regenerated per step %.1f | steps eligible for tail_refactor %.0f, of them with a short walk and patched states %.0f\n",
                                 g_incsub_n, 1e3 * g_incsub[0] / g_incsub_n, 1e3 * g_incsub[1] / g_incsub_n, 1e3 * g_incsub[2] / g_incsub_n, 1e3 * g_incsub[3] / g_incsub_n, 1e3 * g_incsub[4] / g_incsub_n, g_incsub[5] / g_incsub_n, g_incsub[6], g_incsub[7]);
         if (!kst.empty()) {

@@ -383,7 +383,7 @@ def test_many_tiny_and_odd_graphs_agree_with_oracle(lib, oracle):
     assert worst < STATE_ATOL
 
 
-def _random_growth(lib, rng_seed, steps, nthreshold, old_old=False):
+def _random_growth(lib, rng_seed, steps, nthreshold, old_old=False, observe_every=1):
     """grow a pose graph step by step through the reference API: every step adds 1-2 poses with odometry, often loop
     closures to random old poses (full information matrices); old_old: sometimes also a factor between two old poses"""
     rng = np.random.default_rng(rng_seed)
@@ -418,9 +418,23 @@ def _random_growth(lib, rng_seed, steps, nthreshold, old_old=False):
             g.add_factor_xyt(a, b, rel(truth[a], truth[b]) + rng.normal(0, [0.03, 0.03, 0.01]), info())
         p.c.batch_time = 1e300
         g.cholesky_inc(p)
-        trace.append((g.chi2(), g.states()))
+        if step % observe_every == observe_every - 1 or step == steps - 1:
+            trace.append((g.chi2(), g.states()))        # (april_graph_chi2 reads every node: it also brings the library's state mirrors in step)
     p.destroy(); g.destroy()
     return trace
+
+
+@pytest.mark.parametrize("seed,nthreshold", [(4, 10 ** 6), (5, 30)])
+def test_incremental_calls_back_to_back_without_a_chi2_call_in_between(lib, reflib, seed, nthreshold):
+    """A caller that does not evaluate chi^2 between incremental calls: the library's pinned state mirrors and device copies
+    are then kept in step by the library alone (apply_visits moves the mirrors, the next call patches the device copies of
+    the poses it updated -- or loads every state after a full walk).  States compared with the live reference every 25 steps."""
+    ours = _random_growth(lib, seed, 150, nthreshold, observe_every=25)
+    ref = _random_growth(reflib, seed, 150, nthreshold, observe_every=25)
+    assert len(ours) == len(ref) == 6
+    for k, ((c1, s1), (c2, s2)) in enumerate(zip(ours, ref)):
+        assert abs(c1 - c2) <= 1e-6 * max(c2, 1.0), (k, c1, c2)
+        assert np.max(np.abs(s1 - s2)) < 1e-6, k
 
 
 @pytest.mark.parametrize("extend", [1, 0])
