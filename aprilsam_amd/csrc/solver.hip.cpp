@@ -2094,22 +2094,23 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     // its next april_graph_cholesky_inc (refmodel.cpp: the reference's own min-degree order, ~1 ms of integer work on M3500)
     bool model_ready = false;
     if (c.used_inc && gp.host_idx.empty()) { c.model.batch(N, F, gp.h_fa.p, gp.h_fb.p); model_ready = true; }      // (not for params that only ever see batch calls)
+    // ... and the part of the write-back that does not wait for the result: every node is re-linearised at the state it came
+    // in with before anything is solved (aprilsam.c:131-135: l_point = state, whatever the factorisation says later), UID = index
+    // (aprilsam.c:628).  The walk also pulls the node objects into the cache for the second half below.
+    april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
+    for (int i = N - 1; i >= 0; i--) { april_graph_node_t *n = ns[i]; n->UID = i; memcpy(n->l_point, gp.h_state.p + (size_t)3 * i, 24); }
     HIPCHECK(hipStreamSynchronize(gp.stream));
     const double t4 = now_ms();
     check_bad(c);
     c.st.error_code = 0;
-    april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
     if (c.st.not_spd) {
         c.model.valid = false;
         static bool warned = false;
         if (!warned) { fprintf(stderr, "aprilsam_amd: information matrix not positive definite; node states left untouched\n"); warned = true; }
     } else {
-        // write back: l_point = linearisation point used (old state), state/delta_X where not NaN-skipped,
-        // UID = index (aprilsam.c:628)
+        // write back: state / delta_X where not NaN-skipped (l_point and UID went in above)
         for (int i = N - 1; i >= 0; i--) {                                   // aprilsam.c:311-315 order
             april_graph_node_t *n = ns[i];
-            n->UID = i;
-            memcpy(n->l_point, gp.h_state.p + (size_t)3 * i, 24);
             const double *dx = gp.h_dx.p + (size_t)3 * i;
             if (std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2])) continue;   // april_graph_xyt.c:304-305
             memcpy(n->state, gp.h_lp.p + (size_t)3 * i, 24);
