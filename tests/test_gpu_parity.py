@@ -424,6 +424,77 @@ def _random_growth(lib, rng_seed, steps, nthreshold, old_old=False, observe_ever
     return trace
 
 
+def _recent_pose_growth(lib, rng_seed, steps, nthreshold, tail_poses):
+    """growth that lives near the newest poses -- what tail_refactor serves: every step adds 1-3 poses with odometry, often a
+    factor between two of the last 6 poses (either orientation), sometimes a prior on a recent pose or a second factor on
+    the same pair, now and then a loop closure to an old pose (the general path in between)"""
+    rng = np.random.default_rng(rng_seed)
+    lib.set_option("tail_poses", tail_poses)
+    try:
+        g = lib.new_graph(); p = lib.new_param(nthreshold=nthreshold, delta_xy=0.05, delta_theta=0.05)
+        truth = [np.zeros(3)]
+        g.add_node_xyt(truth[0]); g.add_factor_xytpos(0, [0, 0, 0], datasets.PRIOR_W)
+        g.cholesky(p)
+        trace = []
+
+        def rel(a, b):
+            c, s = np.cos(a[2]), np.sin(a[2]); dx, dy = b[0] - a[0], b[1] - a[1]
+            return np.array([c * dx + s * dy, -s * dx + c * dy, b[2] - a[2]])
+
+        def info():
+            M = rng.normal(size=(3, 3)); Wk = M @ M.T + np.diag([40.0, 40.0, 120.0]); return (Wk + Wk.T) / 2
+
+        for step in range(steps):
+            n0 = len(truth)                                   # first pose of this call
+            for _ in range(int(rng.integers(1, 4))):
+                last = truth[-1]
+                new = np.array([last[0] + np.cos(last[2]) * 0.8, last[1] + np.sin(last[2]) * 0.8, last[2] + rng.uniform(-0.6, 0.6)])
+                truth.append(new); n = len(truth) - 1
+                g.add_node_xyt(new + rng.normal(0, [0.15, 0.15, 0.04]))
+                g.add_factor_xyt(n - 1, n, rel(truth[n - 1], new) + rng.normal(0, [0.03, 0.03, 0.01]), info())
+            n = len(truth) - 1
+            if n > 7 and rng.random() < 0.7:
+                for _ in range(int(rng.integers(1, 4))):      # one end is a pose of THIS call (factors between two older poses: see
+                    b = int(rng.integers(n0, n + 1))          # test_factors_between_two_old_poses_against_the_live_reference)
+                    a = int(rng.choice([q for q in range(n - 6, n + 1) if q != b]))
+                    if rng.random() < 0.5:
+                        a, b = b, a
+                    g.add_factor_xyt(a, b, rel(truth[a], truth[b]) + rng.normal(0, [0.03, 0.03, 0.01]), info())
+            if n > 3 and rng.random() < 0.25:
+                o = int(rng.integers(max(0, n - 5), n + 1))
+                g.add_factor_xytpos(o, truth[o] + rng.normal(0, [0.05, 0.05, 0.02]), np.diag([25.0, 25.0, 40.0]))
+            if n > 12 and rng.random() < 0.12:
+                o = int(rng.integers(0, n - 8))
+                g.add_factor_xyt(o, n, rel(truth[o], truth[n]) + rng.normal(0, [0.03, 0.03, 0.01]), info())
+            p.c.batch_time = 1e300
+            g.cholesky_inc(p)
+            trace.append((g.chi2(), g.states()))
+        p.destroy(); g.destroy()
+        return trace
+    finally:
+        lib.set_option("tail_poses", 28)
+
+
+@pytest.mark.parametrize("seed,nthreshold,tail_poses", [(11, 10 ** 6, 28), (12, 40, 28), (13, 10 ** 6, 9), (14, 25, 16)])
+def test_growth_among_the_newest_poses_matches_the_live_reference(lib, reflib, seed, nthreshold, tail_poses):
+    """tail_refactor's territory (several new poses per call, factors among the last few poses in both orientations, priors,
+    repeated pairs) interleaved with loop closures, with short tail fronts too (a tail front fills up and the next one opens
+    every few steps): chi^2 and every state against the unmodified reference, step by step."""
+    ours = _recent_pose_growth(lib, seed, 120, nthreshold, tail_poses)
+    ref = _recent_pose_growth_ref(reflib, seed, 120, nthreshold)
+    for k, ((c1, s1), (c2, s2)) in enumerate(zip(ours, ref)):
+        assert abs(c1 - c2) <= 1e-6 * max(c2, 1.0), (k, c1, c2)
+        assert np.max(np.abs(s1 - s2)) < 1e-6, k
+
+
+def _recent_pose_growth_ref(reflib, seed, steps, nthreshold):
+    class _NoOptions:            # the reference library has no options: same driver, set_option ignored
+        def __init__(self, L): self.L = L
+        def set_option(self, *a): pass
+        def __getattr__(self, k): return getattr(self.L, k)
+    return _recent_pose_growth(_NoOptions(reflib), seed, steps, nthreshold, 28)
+
+
 @pytest.mark.parametrize("seed,nthreshold", [(4, 10 ** 6), (5, 30)])
 def test_incremental_calls_back_to_back_without_a_chi2_call_in_between(lib, reflib, seed, nthreshold):
     """A caller that does not evaluate chi^2 between incremental calls: the library's pinned state mirrors and device copies
