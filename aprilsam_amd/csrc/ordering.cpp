@@ -20,7 +20,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <numeric>
+#include <string>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -243,10 +245,11 @@ struct Dissector {
     // so the tree does not depend on the number of threads.
     size_t par_min = 0; PlanPool *pool = nullptr;
     std::vector<std::unique_ptr<Dissector>> helpers;
-    Dissector &helper(int k) {
+    Dissector &helper(int k) {                           // (created by the calling thread, before the job that uses them starts)
         if (k == 0) return *this;
-        while ((int)helpers.size() < k) helpers.emplace_back(new Dissector(N, ap, ai, xy, leaf, tree, sh));
-        return *helpers[k - 1];
+        if ((int)helpers.size() <= k) helpers.resize(k + 1);
+        for (int q = 1; q <= k; q++) if (!helpers[q]) helpers[q].reset(new Dissector(N, ap, ai, xy, leaf, tree, sh));
+        return *helpers[k];
     }
     int lab(int v) const { return sh.label[v]; }
     void set_lab(int v, int L) { sh.label[v] = L; }
@@ -439,48 +442,65 @@ struct Dissector {
 
     // the split of one connected region of more than `leaf` vertices (null: none found, the region stays a dense node).  A pure
     // function of the region and the graph: it does not touch the tree, and leaves this evaluator's scratch as it found it.
-    Split *best_split(const std::vector<int> &comp, int L) {
-        Split (&cand)[8] = cand_;
-        for (Split &c : cand) { c.ok = false; c.cost = 1e300; }
+    // ---- the split of one connected region, in pieces (so that the pieces of several regions can run side by side) ----------
+    struct CandJob { int slot; double rot; };
+    static int refine_min() { static const int v = getenv("APRILSAM_AMD_ND_REF") ? atoi(getenv("APRILSAM_AMD_ND_REF")) : 4; return v; }
+    // candidates: slot 3 = the BFS level structure (the longest job: first), the others geometric bisections
+    int candidate_jobs(size_t n, CandJob (&jobs)[8]) const {
         static const int T_DIRS = getenv("APRILSAM_AMD_ND_DIRS") ? atoi(getenv("APRILSAM_AMD_ND_DIRS")) : 8;
-        static const int T_REF = getenv("APRILSAM_AMD_ND_REF") ? atoi(getenv("APRILSAM_AMD_ND_REF")) : 4;
-        static const int T_BAND = getenv("APRILSAM_AMD_ND_BAND") ? atoi(getenv("APRILSAM_AMD_ND_BAND")) : 2;
         static const int T_MORE = getenv("APRILSAM_AMD_ND_MORE") ? atoi(getenv("APRILSAM_AMD_ND_MORE")) : 0;      // region size (x leaf) above which 4 more directions are tried
-        // candidates: slot 3 = the BFS level structure (the longest job: first), the others geometric bisections
-        struct Job { int slot; double rot; } jobs[8]; int nj = 0;
+        int nj = 0;
         jobs[nj++] = { 3, 0.0 };
         jobs[nj++] = { 0, 0.0 };                                         // principal axis
-        if ((int)comp.size() > T_DIRS * leaf) {                         // the extra directions only pay near the top of the tree
+        if ((int)n > T_DIRS * leaf) {                                    // the extra directions only pay near the top of the tree
             jobs[nj++] = { 1, 1.5707963267948966 };                      // orthogonal axis
             jobs[nj++] = { 2, 0.7853981633974483 };                      // diagonal
         }
-        if (T_MORE > 0 && (int)comp.size() > T_MORE * leaf) {
+        if (T_MORE > 0 && (int)n > T_MORE * leaf) {
             jobs[nj++] = { 4, 2.356194490192345 };                       // other diagonal
             jobs[nj++] = { 5, 0.39269908169872414 }; jobs[nj++] = { 6, 1.1780972450961724 }; jobs[nj++] = { 7, 1.9634954084936207 };
         }
-        const bool par = pool && par_min > 0 && comp.size() >= par_min;
-        auto eval = [&](Dissector &d, const Job &jb) { if (jb.slot == 3) d.split_bfs(comp, L, cand[3]); else d.split_geometric(comp, L, cand[jb.slot], jb.rot); };
-        if (par) { helper(nj - 1); pool->run(nj, [&](int k, int) { eval(helper(k), jobs[k]); }); }
-        else for (int k = 0; k < nj; k++) eval(*this, jobs[k]);
-        Split *best = nullptr, *second = nullptr;
+        return nj;
+    }
+    // (on THIS evaluator's scratch; the labels may be another evaluator's, shared)
+    void eval_candidate(const std::vector<int> &comp, int L, const CandJob &jb, Split (&cand)[8]) {
+        if (jb.slot == 3) split_bfs(comp, L, cand[3]); else split_geometric(comp, L, cand[jb.slot], jb.rot);
+    }
+    static void choose(Split (&cand)[8], Split *&best, Split *&second) {
+        best = nullptr; second = nullptr;
         for (Split &c : cand) {
             if (!c.ok) continue;
             if (!best || c.cost < best->cost) { second = best; best = &c; }
             else if (!second || c.cost < second->cost) second = &c;
         }
-        if (best && (int)comp.size() > T_REF * leaf) {
-            auto refine = [&](Dissector &d, Split *c) { for (int pass = 0; pass < 2; pass++) { double before = c->cost; d.refine_band(comp, L, *c, T_BAND); if (c->cost >= before) break; } };
+    }
+    void refine_split(const std::vector<int> &comp, int L, Split *c) {
+        static const int T_BAND = getenv("APRILSAM_AMD_ND_BAND") ? atoi(getenv("APRILSAM_AMD_ND_BAND")) : 2;
+        for (int pass = 0; pass < 2; pass++) { double before = c->cost; refine_band(comp, L, *c, T_BAND); if (c->cost >= before) break; }
+    }
+    // the split of one connected region of more than `leaf` vertices (null: none found, the region stays a dense node).  A pure
+    // function of the region and the graph: it does not touch the tree, and leaves this evaluator's scratch as it found it.
+    Split *best_split(const std::vector<int> &comp, int L) {
+        Split (&cand)[8] = cand_;
+        for (Split &c : cand) { c.ok = false; c.cost = 1e300; }
+        CandJob jobs[8]; const int nj = candidate_jobs(comp.size(), jobs);
+        const bool par = pool && par_min > 0 && comp.size() >= par_min;
+        if (par) { helper(nj - 1); pool->run(nj, [&](int k, int) { helper(k).eval_candidate(comp, L, jobs[k], cand); }); }
+        else for (int k = 0; k < nj; k++) eval_candidate(comp, L, jobs[k], cand);
+        Split *best, *second;
+        choose(cand, best, second);
+        if (best && (int)comp.size() > refine_min() * leaf) {
             if (par && second) {
                 // the runner-up is refined at the same time; the rule "only if within 25 % of the REFINED best" is applied afterwards
                 // (a runner-up outside it cannot win refined or not, so its refinement is simply ignored: same result as in sequence)
                 const double second_cost0 = second->cost;
                 helper(1);
-                pool->run(2, [&](int k, int) { refine(helper(k), k == 0 ? best : second); });
+                pool->run(2, [&](int k, int) { helper(k).refine_split(comp, L, k == 0 ? best : second); });
                 if (second_cost0 > 1.25 * best->cost) second = nullptr;
             } else {
                 for (Split *c : { best, second }) {
                     if (!c || (c == second && second->cost > 1.25 * best->cost)) continue;
-                    refine(*this, c);
+                    refine_split(comp, L, c);
                 }
             }
             if (second && second->cost < best->cost) best = second;
@@ -501,7 +521,7 @@ struct Dissector {
     // each either a leaf / dense node or a split into separator + two parts.  nested_dissection computes these level by level
     // (regions of a level side by side) and creates the tree nodes afterwards, in the order run() would have.
     struct CompResult { bool leaf = true; std::vector<int> verts, P0, P1; int c0 = -1, c1 = -1; };      // verts: the leaf, or the separator; c0 / c1: results of the parts (-1: set aside)
-    struct RegionResult { std::vector<CompResult> comps; };
+    struct RegionResult { std::deque<CompResult> comps; };       // (a deque: results are filled in through pointers while more are appended)
     void process_region(const std::vector<int> &verts, RegionResult &out) {
         std::vector<int> &order = comp_order_;
         const int L = new_label();
@@ -522,6 +542,65 @@ struct Dissector {
         }
     }
     std::vector<int> comp_order_;
+
+    // The same for ALL regions of a level that has only a few (the first levels of the tree), with the pieces of their splits
+    // side by side: every candidate of every connected component in one job, every refinement in another.  Components and
+    // labels are this evaluator's; the candidates run on per-thread helpers that share its labels.
+    struct CompWork { std::vector<int> comp; int L = 0; CompResult *out = nullptr; Split cand[8]; Split *best = nullptr, *second = nullptr; double second_cost0 = 0; };
+    void process_regions(const std::vector<const std::vector<int> *> &regions, const std::vector<RegionResult *> &outs) {
+        std::vector<std::unique_ptr<CompWork>> work;
+        std::vector<int> &order = comp_order_;
+        for (size_t r = 0; r < regions.size(); r++) {
+            const std::vector<int> &verts = *regions[r];
+            const int L = new_label();
+            for (int v : verts) set_lab(v, L);
+            for (int s : verts) {
+                if (lab(s) != L) continue;
+                bfs(s, L, order);
+                std::vector<int> comp(order);
+                for (int v : comp) dist[v] = -1;
+                const int Lc = new_label();
+                for (int v : comp) set_lab(v, Lc);
+                std::sort(comp.begin(), comp.end());
+                outs[r]->comps.emplace_back();
+                CompResult &cr = outs[r]->comps.back();
+                if ((int)comp.size() <= leaf) { cr.leaf = true; cr.verts = std::move(comp); continue; }
+                work.emplace_back(new CompWork());
+                work.back()->comp = std::move(comp); work.back()->L = Lc; work.back()->out = &cr;
+            }
+        }
+        if (helpers.size() < (size_t)pool->workers() + 1) helpers.resize((size_t)pool->workers() + 1);
+        auto mine = [&](int who) -> Dissector & {            // evaluator of the executing thread (who = 0: this one)
+            if (who == 0) return *this;
+            if (!helpers[who]) helpers[who].reset(new Dissector(N, ap, ai, xy, leaf, tree, sh));
+            return *helpers[who];
+        };
+        struct J { CompWork *w; CandJob jb; };
+        std::vector<J> jobs;
+        for (auto &w : work) { CandJob cj[8]; const int nj = candidate_jobs(w->comp.size(), cj); for (int k = 0; k < nj; k++) jobs.push_back({ w.get(), cj[k] }); }
+        std::stable_sort(jobs.begin(), jobs.end(), [](const J &a, const J &b) { return (a.jb.slot == 3) > (b.jb.slot == 3); });      // the long ones first
+        pool->run((int)jobs.size(), [&](int k, int who) { mine(who).eval_candidate(jobs[k].w->comp, jobs[k].w->L, jobs[k].jb, jobs[k].w->cand); });
+        struct R { CompWork *w; Split *c; };
+        std::vector<R> refs;
+        for (auto &w : work) {
+            choose(w->cand, w->best, w->second);
+            if (w->best && (int)w->comp.size() > refine_min() * leaf) {
+                refs.push_back({ w.get(), w->best });
+                if (w->second) { w->second_cost0 = w->second->cost; refs.push_back({ w.get(), w->second }); }
+            }
+        }
+        pool->run((int)refs.size(), [&](int k, int who) { mine(who).refine_split(refs[k].w->comp, refs[k].w->L, refs[k].c); });
+        for (auto &w : work) {
+            Split *best = w->best, *second = w->second;
+            if (best && (int)w->comp.size() > refine_min() * leaf) {
+                if (second && w->second_cost0 > 1.25 * best->cost) second = nullptr;      // (as in best_split: the speculative refinement is ignored)
+                if (second && second->cost < best->cost) best = second;
+            }
+            CompResult &cr = *w->out;
+            if (!best) { cr.leaf = true; cr.verts = std::move(w->comp); }
+            else { cr.leaf = false; cr.verts = std::move(best->S); cr.P0 = std::move(best->P0); cr.P1 = std::move(best->P1); }
+        }
+    }
 };
 
 }  // namespace
@@ -589,8 +668,15 @@ void nested_dissection(int N, const std::vector<int> &adj_ptr, const std::vector
             return *ev[who];
         };
         evaluator(0).pool = pool; evaluator(0).par_min = 1;
+        std::string lvl_times;
         while (!level.empty()) {
-            if (level.size() < 3) for (Pending &pd : level) evaluator(0).process_region(pd.verts, *results[pd.res]);
+            const double tl0 = prof ? now() : 0;
+            struct LevelStamp { std::string &out; double t0; size_t n; bool on; std::function<double()> now_; ~LevelStamp() { if (on) { char b[64]; snprintf(b, sizeof b, " %zu:%.3f", n, now_() - t0); out += b; } } } stamp_{ lvl_times, tl0, level.size(), prof, now };
+            if (level.size() < 3) {
+                std::vector<const std::vector<int> *> rv; std::vector<RR *> ro;
+                for (Pending &pd : level) { rv.push_back(&pd.verts); ro.push_back(results[pd.res].get()); }
+                evaluator(0).process_regions(rv, ro);
+            }
             else {
                 evaluator(0).pool = nullptr;            // (no job inside a job: the calling thread takes regions like everybody else)
                 pool->run((int)level.size(), [&](int i, int who) { evaluator(who).process_region(level[i].verts, *results[level[i].res]); });
@@ -605,6 +691,7 @@ void nested_dissection(int N, const std::vector<int> &adj_ptr, const std::vector
                 }
             level.swap(next);
         }
+        if (prof) fprintf(stderr, "aprilsam_amd dissection N=%d, levels of the top of the tree (regions:ms):%s\n", N, lvl_times.c_str());
         // replay: run()'s stack discipline over the results
         struct Ent { int res; std::vector<int> verts; int parent; };
         std::vector<Ent> stack; stack.push_back({ 0, {}, -1 });
