@@ -133,6 +133,11 @@ aprilsam_amd_plan_t *aprilsam_amd_plan_create(int n_nodes, int n_factors, const 
         fprintf(stderr, "aprilsam_amd: ERROR %d: %s\n", e.code, e.msg.c_str());
         delete pl;
         return nullptr;
+    } catch (const std::exception &e) {           // std::bad_alloc from the planner or its pool tasks must not cross the C ABI either
+        asam::set_last_error(asam::ERR_INTERNAL, e.what());
+        fprintf(stderr, "aprilsam_amd: ERROR %d: %s\n", (int)asam::ERR_INTERNAL, e.what());
+        delete pl;
+        return nullptr;
     }
     return pl;
 }

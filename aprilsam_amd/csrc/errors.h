@@ -3,8 +3,8 @@
 // library that drives a GPU must not take the caller's process down with it.  Everything below the C-ABI reports a
 // failure by throwing SolverError; the entry points catch it, leave the caller's node states untouched, print one line
 // on stderr, record code + message (aprilsam_amd_last_error, aprilsam_amd_stats_t::error_code) and drop the param's
-// cached plan so that the next call starts from a clean slate.  The only abort() left is "no HIP device visible":
-// there is no CPU fallback to fall back to, and that has to be loud.
+// cached plan so that the next call starts from a clean slate.  "No HIP device visible" is reported the same way
+// (ERR_NO_DEVICE, on every call): there is no CPU fallback to fall back to, the message says that nothing was computed.
 #pragma once
 #include <string>
 
@@ -18,6 +18,7 @@ enum {
     ERR_OOM = -11,             // device or pinned-host memory exhausted (or the mem_cap_mb option's limit)
     ERR_UNSUPPORTED = -12,     // node type / factor arity / front size this build does not handle
     ERR_BAD_GRAPH = -13,       // malformed input: node index out of range, factor connecting a node to itself
+    ERR_NO_DEVICE = -14,       // no HIP device visible (there is no CPU fallback: the call computed nothing)
     ERR_INTERNAL = -15,        // inconsistency in the planner (a bug, not an input problem)
 };
 

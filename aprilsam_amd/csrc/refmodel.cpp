@@ -207,7 +207,19 @@ void RefModel::inc_begin(int n_nodes, int n_factors, const int *fa, const int *f
     const int oldN = N;
     adj.resize(n_nodes); parent.resize(n_nodes, -1); changed.resize(n_nodes, 0); relin.resize(n_nodes, 0); kids.resize(n_nodes);
     for (int i = oldN; i < n_nodes; i++) { ord.push_back(i); pos.push_back(i); }
-    naffected = 0;
+    naffected = 0; old_old_cross = 0;
+    // A new factor between two poses that both predate this call, neither an ancestor of the other in the tree as it stands
+    // BEFORE the call: the reference's partial re-factorisation walks that old tree children first (aprilsam.c:850-906) and
+    // finalises one pose's rows before the other's have been added to them -- its result is not the solution of its own normal
+    // equations there (tests/test_gpu_api_surface.py pins the distance).  Counted so that the caller can be told.
+    for (int f = F; f < n_factors; f++) {
+        const int u = fa[f], v = fb[f];
+        if (v < 0 || u == v || u >= oldN || v >= oldN) continue;
+        const int lo = pos[u] < pos[v] ? u : v, hi = pos[u] < pos[v] ? v : u;
+        int a = lo;
+        while (a != -1 && a != hi && pos[a] < pos[hi]) a = parent[a];
+        if (a != hi) old_old_cross++;
+    }
     for (int f = F; f < n_factors; f++) {
         const int nodes[2] = { fa[f], fb[f] };
         for (int z0 = 0; z0 < (fb[f] >= 0 ? 2 : 1); z0++) {

@@ -19,6 +19,7 @@ struct RefModel {
     std::vector<unsigned char> changed;     // label_changed
     std::vector<unsigned char> relin;       // label_relinearized
     int start_over = 0, naffected = 0, root = -1;
+    int old_old_cross = 0;                  // inc_begin: new factors between two OLD poses of different branches of the tree (see inc_begin)
 
     void add_factor_edges(int a, int b);
     void set_parent(int v, int p);

@@ -33,14 +33,9 @@ namespace asam {
 // ------------------------------------------------------------------------------------------------------
 // utilities
 // ------------------------------------------------------------------------------------------------------
-// The one failure that still ends the process: no GPU.  There is no CPU fallback to fall back to (see errors.h).
-[[noreturn]] static void fatal(const char *msg) {
-    fprintf(stderr, "aprilsam_amd: FATAL: %s\n", msg);
-    fflush(stderr);
-    abort();
-}
-// every other failure is a SolverError caught at the entry point (guarded() below): states untouched, message on stderr,
-// code kept for aprilsam_amd_last_error / stats.error_code
+// every failure is a SolverError caught at the entry point (guarded() below): states untouched, message on stderr,
+// code kept for aprilsam_amd_last_error / stats.error_code -- "no HIP device" included (ERR_NO_DEVICE): there is no CPU
+// fallback to fall back to, every solver call on such a box fails, loudly, and returns (round 4: no abort() left in the library)
 #define HIPCHECK(expr)                                                                                 \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
@@ -108,11 +103,11 @@ static int device_count() {
 }
 static void ensure_device() {
     static std::once_flag once;
-    std::call_once(once, [] {
+    std::call_once(once, [] {           // (an exception leaves the flag unset: the next call looks again)
         load_env_options();
         int n = device_count();
-        if (n <= 0) fatal("no HIP device visible: the april_graph_cholesky* / april_graph_chi2 entry points of "
-                          "libaprilsam_amd.so run on an AMD GPU only (there is no CPU fallback)");
+        if (n <= 0) fail(ERR_NO_DEVICE, "no HIP device visible: the april_graph_cholesky* / april_graph_chi2 entry points of "
+                         "libaprilsam_amd.so run on an AMD GPU only (there is NO CPU fallback: nothing was computed)");
         if (g_device < 0) {
             const char *lr = getenv("LOCAL_RANK");
             g_device = lr ? atoi(lr) % n : 0;
@@ -190,7 +185,9 @@ struct PatchList {
 // ------------------------------------------------------------------------------------------------------
 // packed graph (SoA, host pinned + device) — one per april_graph_t pointer
 // ------------------------------------------------------------------------------------------------------
+static long long g_pack_serial = 0;
 struct GraphPack {
+    const long long serial = ++g_pack_serial;      // captured hipGraphs are keyed by it: a pack freed and another allocated at the same addresses must not match
     int N = 0, F = 0;                  // packed counts
     std::vector<const void *> fptr;    // factor object pointers already packed (cache validation)
     std::vector<int> pending;          // poses whose pinned state mirror is ahead of the device copy (written by apply_visits)
@@ -565,14 +562,16 @@ struct Context {
     DBuf<int> d_solve_tab; std::vector<int> solve_tab;      // april_graph_cholesky_inc_solver: front lists of its back substitution
     hipGraphExec_t gexec = nullptr;
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
+    long long gexec_serial = 0;
     // the same phase as the API call runs it: first kernel reads the caller's states from the pinned mirror, last kernel
     // writes new states / dx / pivot flag back to pinned mirrors -- one graph launch + one stream sync per call
     hipGraphExec_t gexec_api = nullptr;
-    const void *api_key[6] = {};
+    const void *api_key[7] = {};
     double lambda_val = -1; int lambda_N = -1;     // what d_lambda currently holds (uniform batch value), -1: unknown
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
-        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release(); d_flags.release(); d_flevel.release(); d_perm.release(); d_solve_tab.release(); d_dinv.release(); d_bsb_far.release(); d_bsb_flags.release();
+        d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release();
+        h_done.release(); h_kstamp.release(); d_prof.release(); d_flags.release(); d_flevel.release(); d_perm.release(); d_solve_tab.release(); d_dinv.release(); d_bsb_far.release(); d_bsb_flags.release();
         if (gexec) (void)hipGraphExecDestroy(gexec);
         gexec = nullptr;
         if (gexec_api) (void)hipGraphExecDestroy(gexec_api);
@@ -1227,7 +1226,7 @@ static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp
     if (timing && !c.have_events) { for (auto &e : c.ev) HIPCHECK(hipEventCreate(&e)); c.have_events = true; }
     if (io_host) {
         if (g_opt.use_graph && !timing && gp.host_idx.empty()) {
-            const void *key[6] = { gp.d_state.p, gp.h_state.p, gp.h_lp.p, gp.h_dx.p, c.h_bad.p, (const void *)(size_t)gp.N };
+            const void *key[7] = { gp.d_state.p, gp.h_state.p, gp.h_lp.p, gp.h_dx.p, c.h_bad.p, (const void *)(size_t)gp.N, (const void *)(size_t)gp.serial };
             if (!c.gexec_api || memcmp(key, c.api_key, sizeof(key)) != 0) {
                 if (c.gexec_api) { (void)hipGraphExecDestroy(c.gexec_api); c.gexec_api = nullptr; }
                 hipGraph_t graph = nullptr;
@@ -1245,7 +1244,7 @@ static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp
         return;
     }
     if (g_opt.use_graph && !timing && !unary_at_lp && gp.host_idx.empty()) {   // (host-evaluated factors: staging buffers may move)
-        if (!c.gexec || c.gexec_key != (const void *)gp.d_state.p) {
+        if (!c.gexec || c.gexec_key != (const void *)gp.d_state.p || c.gexec_serial != gp.serial) {
             if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
             hipGraph_t graph = nullptr;
             HIPCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -1253,7 +1252,7 @@ static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp
             HIPCHECK(hipStreamEndCapture(s, &graph));
             HIPCHECK(hipGraphInstantiate(&c.gexec, graph, nullptr, nullptr, 0));
             HIPCHECK(hipGraphDestroy(graph));
-            c.gexec_key = (const void *)gp.d_state.p;
+            c.gexec_key = (const void *)gp.d_state.p; c.gexec_serial = gp.serial;
         }
         HIPCHECK(hipGraphLaunch(c.gexec, s));
     } else {
@@ -1347,6 +1346,9 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     IncState &I = c.inc; Plan &P = c.plan;
     const bool batch = batch_lambda >= 0;
     if (!I.ready || N < I.Nb || Fold < I.Fb) return false;
+    // an option that launch tables, front layouts (tail_poses: the padded shape of the last tail front) or captured graphs depend
+    // on changed since this plan was made: the frozen base + tail structures were built under the old values -- full re-plan
+    if (c.plan_persist != launch_table_key()) return false;
     const int Nb = I.Nb, nF0 = I.nF0, m = N - Nb;
     if (m > I.cap_nodes - 8 || F - I.Fb > I.cap_fact - 8 || m < 1) return false;
     const int *fa = gp.h_fa.p, *fb = gp.h_fb.p;
@@ -2019,7 +2021,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
                      (int)gp.fptr.size() == gp.F && gp.host_idx.empty() && gp.F_on_device == gp.F && gp.dirty_hi <= gp.dirty_lo &&
                      c.patN == gp.N && (int)c.pat.size() == 2 * gp.F && c.inc.t_first.empty() && c.plan_persist == launch_table_key() &&
                      c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last && g_opt.use_graph && !param->show_timing && !c.no_speculation;
-    c.no_speculation = false; c.st.reserved1 = 0;
+    c.no_speculation = false; c.st.reserved1 = 0; c.st.inc_replanned = 0; c.st.inc_old_old_cross = 0;
     if (!speculate) pack_factors(gp, g);
     pack_states(gp, g, false, false);
     gp.mirror_sync = false;                           // (a batch step leaves new states in d_state and in the l_point mirror)
@@ -2272,6 +2274,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         inc_prepare(c);
     }
     c.inc_F = F; c.inc_N = N; c.same_topo_batches = 0;
+    c.st.inc_replanned = reused ? 0 : 1; c.st.inc_old_old_cross = c.model.old_old_cross;      // (include/aprilsam_amd.h: what the caller is told)
     const double tp4 = now_ms();
     if (!reused) {                // (the fast path's last kernel wrote states, dx and the pivot flag into the pinned mirrors itself)
         HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, gp.stream));
@@ -2335,7 +2338,9 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         c.model.start_over = (int)(0x7fffffffu + (unsigned)(c.model.start_over - start_over_before));
     if (c.model.start_over > param->nthreshold) {                                                   // aprilsam.c:566-575
         const double b0 = now_ms();
+        const int rp = c.st.inc_replanned, oc = c.st.inc_old_old_cross;
         batch_impl(g, param);
+        c.st.inc_replanned = rp; c.st.inc_old_old_cross = oc;       // (they describe the incremental step this call made first)
         param->batch_time = now_ms() - b0;
     }
 }
@@ -3025,7 +3030,8 @@ long long shard_info(const april_graph_cholesky_param_t *param, int what, long l
 
 // ---- attaching a transport --------------------------------------------------------------------------------------
 int shard_comm_unique_id(char *out128) {
-    ensure_device();
+    const int dev_rc = guarded_rc(nullptr, nullptr, [&] { ensure_device(); return 0; });
+    if (dev_rc) return dev_rc;
     if (!g_rccl.load()) return -5;
     ncclUniqueId id;
     const ncclResult_t r = g_rccl.GetUniqueId(&id);

@@ -24,7 +24,9 @@ class HostComm(C.Structure):
 
 
 class ShardedSolver:
-    def __init__(self, lib, graph, param, rank, world, backend="nccl", device=None):
+    def __init__(self, lib, graph, param, rank, world, backend="nccl", device=None, _pretend_rccl_unavailable_on=None):
+        # (_pretend_rccl_unavailable_on: tests only -- that rank reports "librccl not loadable", to walk the fall-back)
+        self._pretend_unavailable = _pretend_rccl_unavailable_on
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -76,10 +78,18 @@ class ShardedSolver:
         if self.world <= 1:
             return mine
         torch, dist = self.torch, self.dist
-        dev = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+        dev = self._coll_device(device)
         t = torch.tensor([1 if mine else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t.item()))
+
+    def _coll_device(self, device):
+        """where tensors of the launcher's own collectives live: the (current) GPU under an nccl group, the host otherwise -- one
+        rule for every collective of the set-up, so that no rank can take a different turn"""
+        torch, dist = self.torch, self.dist
+        if dist.get_backend() != "nccl":
+            return "cpu"
+        return device if device is not None else torch.device("cuda", torch.cuda.current_device())
 
     # -- transports ---------------------------------------------------------------------------------------------------
     def _init_rccl(self, device):
@@ -89,14 +99,12 @@ class ShardedSolver:
         torch, dist = self.torch, self.dist
         buf = C.create_string_buffer(128)
         rc = self.lib.dll.aprilsam_amd_shard_comm_unique_id(buf)          # (loads librccl next to the library's HIP runtime)
-        import os
-        if os.environ.get("APRILSAM_AMD_TEST_RCCL_UNAVAILABLE") == str(self.rank):      # tests: this rank pretends it cannot load RCCL
+        if self._pretend_unavailable is not None and int(self._pretend_unavailable) == self.rank:
             rc = -5
         if not self._all_ok(rc == 0, device):
             raise RuntimeError(f"librccl not usable on every rank (shard_comm_unique_id rc={rc} here)")
         if self.world > 1:
-            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-            t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=dev if dist.get_backend() == "nccl" else "cpu")
+            t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=self._coll_device(device))
             dist.broadcast(t, src=0)                                        # rank 0's id wins
             buf = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
         rc = self.lib.dll.aprilsam_amd_shard_comm_init_rccl(self._p, buf)

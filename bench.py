@@ -318,6 +318,54 @@ def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iter
     return res
 
 
+def headline_into_config(out):
+    """The driver's record keeps `config` and `roofline` whole and only the NAMES of the other extras, so every number a
+    reader needs to judge the run is copied there: SURVEY.md section 8(d)'s metric (one warm april_graph_cholesky call through
+    the C-ABI, host objects in -> states valid in the host objects), the cold call, config 3 (incremental demo), config 4
+    (100k lattice) and config 5 (1M lattice: ms per iteration at this run's N ranks = the strong-scaling figure, transport as
+    the communication library reports it).  `value` itself stays what the bench contract defines: K steps with the inputs
+    resident in HBM when the timed region starts (a rate that includes the hand-over of host buffers is never `value`)."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+    cfg = out["config"]
+    cfg["value_is"] = "resident loop (bench contract: inputs in HBM when the timed region starts); api_call_* = SURVEY 8(d)'s metric"
+    cfg["api_call_it_per_s"] = out.get("value_api_call"); cfg["ms_per_api_call"] = out.get("ms_per_api_call")
+    api = out.get("api", {})
+    if "default" in api:
+        cfg["api_call_warm_ms_median"] = api["default"]["warm_ms_per_call"]; cfg["api_call_cold_ms"] = api.get("cold_ms_per_call")
+    if "cpu_baseline" in out:
+        cfg["api_call_speedup_vs_reference_cpu"] = out.get("speedup_vs_cpu_baseline")
+    cfg["factorise_ms"] = out.get("factorise_ms")
+    l100 = out.get("lattice100k", {})
+    cfg["lattice100k"] = pick(l100, ("ms_per_step", "factor_tflops", "chi2_relerr_vs_reference", "speedup_vs_reference_cpu", "error"))
+    if isinstance(l100.get("kernels_ms_per_step"), dict):
+        cfg["lattice100k"]["kernels_ms_per_step"] = l100["kernels_ms_per_step"]
+    l1m = out.get("lattice1m", {})
+    cfg["lattice1m"] = pick(l1m, ("ms_per_step", "n_gpus", "factor_tflops", "parallelism", "chi2_relerr_vs_single_gpu", "modelled_critical_path",
+                                  "comm_bytes_per_iteration", "error"))
+    if isinstance(l1m.get("comm"), dict):
+        cfg["lattice1m"]["comm"] = pick(l1m["comm"], ("transport", "ncclCommCount", "ncclCommUserRank", "rccl_version", "librccl"))
+    if isinstance(l1m.get("kernels_ms_per_step"), dict):
+        cfg["lattice1m"]["kernels_ms_per_step"] = l1m["kernels_ms_per_step"]
+    inc = out.get("m3500_incremental", {})
+    cfg["m3500_incremental"] = pick(inc, ("total_ms", "median_ms", "mean_ms", "p99_ms", "batch_fallbacks", "fallback_schedule_identical",
+                                           "chi2_max_relerr_vs_reference", "speedup_total_vs_reference", "error"))
+    if isinstance(inc.get("reference_cpu_same_host"), dict):
+        cfg["m3500_incremental"]["reference_cpu"] = pick(inc["reference_cpu_same_host"], ("total_ms", "median_ms"))
+    if isinstance(inc.get("where_the_time_goes"), dict):
+        cfg["m3500_incremental"]["where_the_time_goes"] = inc["where_the_time_goes"]
+    gb = out.get("m3500_batch_update_only", {})
+    cfg["m3500_batch_update_only"] = pick(gb, ("total_ms", "mean_ms", "speedup_total_vs_reference", "error"))
+    # the per-kernel roofline fractions of the lattices ride in `roofline` (kept whole as well)
+    roof = out["roofline"]
+    for tag, blk in (("lattice100k", l100), ("lattice1m", l1m)):
+        rows = []
+        for r in (blk.get("roofline") or []) + (blk.get("roofline_hbm") or []):
+            rows.append(pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step", "traffic_over_algorithmic")))
+        if rows:
+            roof[tag] = rows
+
+
 def aggregate_value(world, steps, max_dt):
     """whole-job throughput of `world` independent replicas: GN iterations / s"""
     return world * steps / max_dt
@@ -568,6 +616,7 @@ def main():
         def give_up():
             if rank == 0:
                 out["lattice1m"] = {"error": "watchdog: sharded solve did not finish in 240 s", "n_gpus": world}
+                headline_into_config(out)
                 print(json.dumps(out), flush=True)
             os._exit(0)
         dog = threading.Timer(240.0, give_up); dog.daemon = True; dog.start()
@@ -577,6 +626,7 @@ def main():
             out["lattice1m"] = {"error": repr(e), "n_gpus": world}
         dog.cancel()
     if rank == 0:
+        headline_into_config(out)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

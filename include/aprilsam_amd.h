@@ -198,7 +198,7 @@ april_graph_t *aprilsam_amd_graph_load(const char *path);
  * outer-blocked trailing update, packed Schur offsets, panel row tiles, LDS budgets).  0 = all good.  No GPU needed. */
 int aprilsam_amd_selftest(void);
 
-/* Number of usable HIP devices (0 => every solver entry point fails loudly). */
+/* Number of usable HIP devices (0 => every solver entry point fails loudly: error -14, see below). */
 int aprilsam_amd_device_count(void);
 /* Select the HIP device used by contexts created afterwards (default: LOCAL_RANK env or 0). */
 int aprilsam_amd_set_device(int device);
@@ -219,12 +219,19 @@ typedef struct aprilsam_amd_stats {
     double chi2_before;                /* chi^2 at the linearisation point (from the linearise kernel) */
     int    error_code;                 /* 0, or the code of the failure that ended the last call on this param (see below) */
     int    reserved1;          /* 1: a warm batch call launched on the packed factor copies, found an edited factor object afterwards and ran again (speculate_factors) */
+    /* last april_graph_cholesky_inc on this param (both 0 after any other call): */
+    int    inc_replanned;      /* 1: the step did not fit the frozen plan of the last batch step and was solved on a fresh plan (ordering +
+                                  symbolic analysis + every front factorised); the result is the exact solve of the incremental system */
+    int    inc_old_old_cross;  /* number of the step's new factors that connect two poses which BOTH predate the call and lie in different
+                                  branches of the reference's elimination tree.  For those the reference's partial re-factorisation
+                                  (aprilsam.c:850-906, children first over the OLD tree) finalises one row before the other has updated it and
+                                  returns something that is NOT the solution of its own normal equations; this library returns the exact solve
+                                  (INTEGRATION.md section 6).  > 0 therefore means: this step's states deviate from the reference's by design */
 } aprilsam_amd_stats_t;
 int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_amd_stats_t *out);
 
 /* Failure path.  The reference's entry points are void and crash on bad input (assert / NULL dereference, SURVEY.md
- * section 8(b)); this library never takes the caller's process down (one exception: no HIP device at all -- there is no CPU
- * fallback, the first solver call aborts with a message).  A call that fails returns with the caller's node states
+ * section 8(b)); this library never takes the caller's process down.  A call that fails returns with the caller's node states
  * untouched, prints one line on stderr, and leaves
  *     -2  a pivot was not positive (stats.not_spd = 1; information matrix not positive definite)
  *     -9  a multi-level launch gave up waiting for a dependency flag (should not happen; reported, not hung)
@@ -232,6 +239,8 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *    -12  unsupported input: node type other than xyt, factor with more than two nodes, an unsplittable dense region of
  *         more than ~6000 poses, more than 22 million factors, param->nreordering == 0 (the reference asserts)
  *    -13  malformed graph: node index out of range, a factor connecting a node to itself, incomplete eval() result
+ *    -14  no HIP device visible: there is NO CPU fallback, every solver call on such a machine fails this way (april_graph_chi2
+ *         returns NaN) -- nothing is ever computed on the host
  *    -15  internal inconsistency of the planner
  * in stats.error_code and in aprilsam_amd_last_error (most recent failure of the process; msg may be NULL).  The param's
  * cached plan and factorisation are dropped: the next april_graph_cholesky starts from scratch, april_graph_cholesky_inc
@@ -241,7 +250,10 @@ void aprilsam_amd_clear_error(void);
 
 /* Runtime options (also settable by env APRILSAM_AMD_<NAME>): returns 0 on success.
  *   "leaf_nodes"        nested-dissection leaf size in pose nodes (default 16)
- *   "deterministic"     1 = disable the wall-clock fallback rule aprilsam.c:557 (default 1)
+ *   "deterministic"     1 = disable the wall-clock fallback rule aprilsam.c:557-559; default 0 = the reference's behaviour: an incremental step
+ *                       that took longer than param->batch_time / 3 falls back to a batch step, so the schedule of fall-backs (and with it
+ *                       the states, within the solver's tolerance) depends on the machine's timing exactly as the reference's does.  Parity
+ *                       runs and recorded schedules set 1 (env APRILSAM_AMD_DETERMINISTIC=1)
  *   "use_graph"         1 = replay the numeric phase from a captured hipGraph (default 1)
  *   "device_timing"     1 = record per-stage HIP events (default 0)
  *   "trust_factor_cache" 1 = z/W of already-packed factors are treated as immutable: skips the per-call re-read and
@@ -260,8 +272,9 @@ void aprilsam_amd_clear_error(void);
  *   "syrk128_rows"      trailing updates at least this tall use the LDS-staged 128x128 MFMA kernel (default off)
  *   "batch_extend"      1 (default): april_graph_cholesky on a graph that only GREW since the last plan keeps the plan -- the
  *                       appended poses become tail fronts, every front is re-factorised (batch semantics) -- instead of a new
- *                       ordering + symbolic analysis per call; "extend_tail_fronts" (default 8) tail fronts of 24 poses later,
- *                       or when the topology stops changing, a full re-plan follows.  0 = re-plan on every topology change
+ *                       ordering + symbolic analysis per call; once more than "extend_tail_fronts" (default 8) x 24 poses have been
+ *                       appended (the unit is fixed at 24 poses whatever "tail_poses" -- default 28 -- says), or when the topology stops
+ *                       changing, a full re-plan follows.  0 = re-plan on every topology change
  *   "pin_last"          k > 0: the k newest poses are kept out of the nested dissection and form the root front ("recent
  *                       poses last", cf. aprilsam.c:1021-1098); default 0, measured effect in profiles/r02_inc_hist.json
  *   "speculate_factors" 1 (default): a warm april_graph_cholesky call on an unchanged graph launches the step on the packed factor

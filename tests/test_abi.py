@@ -96,18 +96,30 @@ def test_lattice_generator_counts_and_determinism(lib):
 
 
 def test_solver_entry_points_fail_loudly_without_gpu(lib):
-    """No CPU fallback: on a box without a HIP device the solver aborts with a message (checked in a
-    subprocess so the abort does not take pytest down)."""
+    """No CPU fallback: on a box without a HIP device every solver entry point refuses, loudly -- one ERROR line on stderr per
+    call saying that nothing was computed, code -14 in aprilsam_amd_last_error and stats.error_code, chi^2 = NaN -- and
+    RETURNS with the caller's node states untouched (round 4: the library no longer aborts the host process).  Run in a
+    subprocess to read its stderr."""
     if lib.device_count() > 0:
         pytest.skip("a GPU is visible")
     import subprocess, sys
-    code = ("import sys; sys.path.insert(0, %r)\n"
+    code = ("import sys, math; sys.path.insert(0, %r)\n"
+            "import ctypes as C\n"
             "from aprilsam_amd import host, datasets\n"
             "l = host.SolverLib(); g = l.new_graph(); g.build_from_arrays(*datasets.random_pose_graph(5, 2, 0))\n"
-            "p = l.new_param(); g.cholesky(p); print('RETURNED')\n") % ROOT
+            "before = g.states().copy()\n"
+            "p = l.new_param(); g.cholesky(p)\n"
+            "assert (g.states() == before).all(), 'states were touched'\n"
+            "msg = C.create_string_buffer(256); rc = l.dll.aprilsam_amd_last_error(msg, 256)\n"
+            "assert rc == -14 and b'no HIP device' in msg.value, (rc, msg.value)\n"
+            "assert p.stats()['error_code'] == -14\n"
+            "g.cholesky_inc(p); assert (g.states() == before).all()\n"
+            "assert math.isnan(g.chi2())\n"
+            "assert l.dll.aprilsam_amd_resident_begin(g.ptr, p.ptr) == -14\n"
+            "print('RETURNED')\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "RETURNED" not in r.stdout
-    assert "no HIP device" in r.stderr
+    assert r.returncode == 0 and "RETURNED" in r.stdout, (r.stdout, r.stderr)
+    assert r.stderr.count("no HIP device") >= 3 and "NO CPU fallback" in r.stderr
 
 
 def test_shared_index_arithmetic_selftest(lib):

@@ -211,11 +211,12 @@ def _old_old_case(L, oracle, seed, a, b, nbase=40):
     p.c.batch_time = 1e300
     g.cholesky_inc(p)
     after = g.states()
+    flags = p.stats() if L.is_product else None           # (what the caller is told: stats.inc_old_old_cross / inc_replanned)
     fa2 = np.append(fa, a).astype(np.int32); fb2 = np.append(fb, b).astype(np.int32)
     dx = oracle.solve_system(lp, lp, fa2, fb2, np.vstack([z, zz]), np.vstack([W.reshape(-1, 9), Wk]), np.full(len(st), 1e-4))
     exact = lp + dx; exact[:, 2] = [oracle.mod2pi(v) for v in exact[:, 2]]
     p.destroy(); g.destroy()
-    return after, exact, before
+    return (after, exact, before, flags) if flags is not None else (after, exact, before)
 
 
 def test_factors_between_two_old_poses_against_the_live_reference(lib, reflib, oracle):
@@ -235,7 +236,7 @@ def test_factors_between_two_old_poses_against_the_live_reference(lib, reflib, o
     for seed in range(14):
         rng = np.random.default_rng(seed)
         a, b = sorted(rng.choice(np.arange(1, 39), 2, replace=False).tolist())
-        ours, exact, before = _old_old_case(lib, oracle, seed, a, b)
+        ours, exact, before, flags = _old_old_case(lib, oracle, seed, a, b)
         ref, exact2, _ = _old_old_case(reflib, oracle, seed, a, b)
         assert np.max(np.abs(exact - exact2)) < 1e-12
         touched = np.any(ref != before, axis=1)          # the poses the reference's walk updated
@@ -247,13 +248,78 @@ def test_factors_between_two_old_poses_against_the_live_reference(lib, reflib, o
         if d_ref < 1e-8:
             same_branch += 1
             assert np.max(np.abs(ours - ref)) < 1e-6, seed
+            assert flags["inc_old_old_cross"] == 0, (seed, flags)
         else:
             cross += 1
+            # the deviation is REPORTED: the caller reads from the stats that this step's states are the exact solve, not the
+            # reference's (include/aprilsam_amd.h)
+            assert flags["inc_old_old_cross"] == 1 and flags["inc_replanned"] == 1, (seed, flags)
             worst_ref = max(worst_ref, d_ref); worst_ours = max(worst_ours, d_ours)
     print(f"old-old factors: {same_branch} cases where the reference is exact (identical here), {cross} cross-branch cases: "
           f"max distance to the exact solve  reference {worst_ref:.3e}  this library {worst_ours:.3e}")
     assert same_branch >= 2 and cross >= 2
     assert worst_ref > 1e-4 and worst_ours < 1e-8
+
+
+def test_a_nan_delta_skips_that_pose_on_the_device_as_the_reference_does(lib, reflib):
+    """april_graph_xyt.c:304-305: a node whose dx holds a NaN is skipped by update() -- state AND delta_X stay.  Driven through the
+    DEVICE guards here (the state update that rides on the back substitution, kernels.hip.h backsolve_finish, and
+    k_update_states), not through the host vtable: a pose of its own connected component whose only factor is a prior with a
+    NaN in z gets dx = NaN from the solve, everything else is unaffected.  Both the API call (host objects in/out) and the
+    resident loop (states never leave HBM between the iterations: only the device guard can protect the pose) against the
+    live reference."""
+    st, fa, fb, z, W = datasets.random_pose_graph(40, 14, 5)
+    lone = len(st)                                           # one more pose, connected to nothing ...
+    st = np.vstack([st, [3.0, -2.0, 0.4]])
+    fa = np.append(fa, lone).astype(np.int32); fb = np.append(fb, -1).astype(np.int32)
+    z = np.vstack([z, [np.nan, 0.5, 0.1]]); W = np.vstack([W.reshape(-1, 9), np.diag([10.0, 10.0, 10.0]).reshape(1, 9)])   # ... but to a prior with a NaN
+    out = {}
+    for name, L in (("ours", lib), ("ref", reflib)):
+        g = L.new_graph(); g.build_from_arrays(st, fa, fb, z, W); p = L.new_param()
+        d0 = g.deltas().copy()
+        for _ in range(3):
+            g.cholesky(p)
+        out[name] = (g.states().copy(), g.deltas().copy(), d0)
+        p.destroy(); g.destroy()
+    so, do, d0 = out["ours"]; sr, dr, _ = out["ref"]
+    assert np.array_equal(sr[lone], st[lone]) and np.array_equal(dr[lone], d0[lone])          # the reference skipped the pose ...
+    assert np.array_equal(so[lone], st[lone]) and np.array_equal(do[lone], d0[lone])          # ... and so did this library
+    assert not np.isnan(so).any() and np.max(np.abs(so - sr)) < 1e-6 and np.max(np.abs(do[:lone] - dr[:lone])) < 1e-6
+    assert np.max(np.abs(so[:lone] - st[:lone])) > 1e-3                                       # (the others did move)
+    # resident loop: three iterations on the device, states written back once at the end
+    g = lib.new_graph(); g.build_from_arrays(st, fa, fb, z, W); p = lib.new_param()
+    g.batch_resident(p, 3)
+    s3 = g.states()
+    assert np.array_equal(s3[lone], st[lone]) and not np.isnan(s3).any()
+    assert np.max(np.abs(s3 - sr)) < 1e-6
+    assert p.stats()["not_spd"] == 0
+    p.destroy(); g.destroy()
+
+
+def test_tail_poses_changed_between_two_incremental_steps_forces_a_replan(lib, reflib):
+    """the frozen base + tail plan of the incremental path bakes in option tail_poses (the padded shape of the last
+    tail front).  Raising it between two april_graph_cholesky_inc calls must not drive the old layout with the new value: the
+    step re-plans (stats.inc_replanned) and the run stays on the live reference's states."""
+    try:
+        runs = []
+        for L in (lib, reflib):
+            w = Walk(L, 23)
+            snaps = []
+            for k in range(60):
+                w.grow()
+                if L.is_product and k == 20:
+                    lib.set_option("tail_poses", 40)
+                w.inc()
+                if L.is_product and k == 20:
+                    assert w.p.stats()["inc_replanned"] == 1
+                if L.is_product and k == 22:
+                    assert w.p.stats()["inc_replanned"] == 0
+                snaps.append(w.snap())
+            runs.append(snaps); w.close()
+        for k, (a, b) in enumerate(zip(*runs)):
+            _same(a, b, 1e-6, f"step {k}")
+    finally:
+        lib.set_option("tail_poses", 28)
 
 
 # ---- failure path --------------------------------------------------------------------------------------------------------

@@ -26,7 +26,8 @@ def _worker(rank, world, port, K, iters, out, backend="gloo", env=None):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = host.SolverLib()
     g = lib.new_graph(); lib.dll.aprilsam_amd_make_lattice(g.ptr, K); p = lib.new_param()
-    sol = ShardedSolver(lib, g, p, rank, world, backend=backend)
+    pretend = (env or {}).get("PRETEND_RCCL_UNAVAILABLE_ON")
+    sol = ShardedSolver(lib, g, p, rank, world, backend=backend, _pretend_rccl_unavailable_on=pretend)
     if env:
         assert sol.transport_note and "host callbacks over gloo" in sol.comm_info()["transport"], sol.comm_info()
     chi2 = [sol.chi2()]
@@ -130,7 +131,7 @@ def test_rccl_unavailable_on_one_rank_falls_back_to_host_callbacks_everywhere(bu
     K = 24
     G = np.load(os.path.join(ROOT, "tests", "golden", f"lattice_{K}.npz"))
     iters = len(G["chi2"]) - 1
-    res, st = _run(2, K, iters, backend="nccl", env={"APRILSAM_AMD_TEST_RCCL_UNAVAILABLE": "1"})
+    res, st = _run(2, K, iters, backend="nccl", env={"PRETEND_RCCL_UNAVAILABLE_ON": "1"})
     c1, s1 = _single_gpu_states(lib, K, iters)
     _check(res, st, 2, G["chi2"], s1)
 
