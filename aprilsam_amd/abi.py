@@ -61,7 +61,7 @@ class Stats(C.Structure):
                 ("ms_device", C.c_double), ("ms_d2h", C.c_double), ("ms_unpack", C.c_double),
                 ("ms_total", C.c_double), ("ms_dev_linearize", C.c_double), ("ms_dev_factor", C.c_double),
                 ("ms_dev_solve", C.c_double), ("chi2_before", C.c_double), ("error_code", C.c_int), ("reserved1", C.c_int),
-                ("inc_replanned", C.c_int), ("inc_old_old_cross", C.c_int)]
+                ("inc_replanned", C.c_int), ("inc_old_old_cross", C.c_int), ("inc_fronts_updated", C.c_int), ("reserved2", C.c_int)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -18,6 +18,7 @@ struct Options {
     int inc_one_up = 3, inc_one_dn = 4, inc_one_threads = 512, inc_one_spin = 1;
     int inc_tail = 1;             // ... and steps whose factors touch the last few poses of the last tail front alone re-factorise its trailing columns only
     int inc_inline = 1;           // ... a small step's table / factor / state patches travel in the kernel arguments instead of being read across PCIe
+    int inc_update = 1;           // ... and the fronts on the root path of a loop closure take a low-rank UPDATE of their factor (front_update_body) instead of being re-assembled and re-factorised
     int speculate_factors = 1;    // warm batch calls: the pass over the factor objects (edits in place) runs under the GPU's work on the packed copies; an edit voids the run
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
     int small_threads = 1024;     // workgroup size of k_front_small (256 / 512 / 1024) on latency-bound levels ...

@@ -77,6 +77,7 @@ static void load_env_options() {
         v = g_opt.inc_one_spin; envd("APRILSAM_AMD_INC_ONE_SPIN", &v); g_opt.inc_one_spin = (int)v;
         v = g_opt.inc_tail; envd("APRILSAM_AMD_INC_TAIL", &v); g_opt.inc_tail = (int)v;
         v = g_opt.inc_inline; envd("APRILSAM_AMD_INC_INLINE", &v); g_opt.inc_inline = (int)v;
+        v = g_opt.inc_update; envd("APRILSAM_AMD_INC_UPDATE", &v); g_opt.inc_update = (int)v;
         v = g_opt.speculate_factors; envd("APRILSAM_AMD_SPECULATE_FACTORS", &v); g_opt.speculate_factors = (int)v;
         v = g_opt.block_factor; envd("APRILSAM_AMD_BLOCK_FACTOR", &v); g_opt.block_factor = (int)v;
         v = g_opt.fused_panel; envd("APRILSAM_AMD_FUSED_PANEL", &v); g_opt.fused_panel = (int)v;
@@ -500,6 +501,10 @@ struct IncState {
     // staging for the per-step uploads (members: the async copies read them until the step's final sync)
     std::vector<int> st_i32, st_tab, st_sb, st_sr, st_ids; std::vector<DestRec> st_dest; std::vector<ChildRec> st_child;
     std::vector<unsigned char> st_sw; std::vector<double> st_zeros; std::vector<char> need;
+    // low-rank updates of the fronts on a loop closure's root path (front_update_body, option inc_update)
+    std::vector<char> stale;                // per front: its destination / child records on the device lack what update steps folded in directly
+    bool upd_ok = true;                     // false after a step that failed half-way, until the next full plan
+    std::vector<char> st_mid, st_mode; std::vector<int> st_owner, st_mask, st_wout, st_slot; std::vector<UpdRec> st_upd, st_rec;
 };
 
 struct Context {
@@ -560,6 +565,7 @@ struct Context {
     DBuf<int> d_flags, d_flevel, d_perm;
     DBuf<double> d_dinv, d_bsb_far; DBuf<int> d_bsb_flags;   // inverse diagonal blocks of the big fronts; scratch of k_backsolve_blk
     DBuf<int> d_solve_tab; std::vector<int> solve_tab;      // april_graph_cholesky_inc_solver: front lists of its back substitution
+    DBuf<UpdRec> d_upd; DBuf<double> d_wbuf;               // incremental steps: update records per launch-list entry, the step's travelling vectors
     hipGraphExec_t gexec = nullptr;
     const void *gexec_key = nullptr;      // GraphPack the graph was captured against
     long long gexec_serial = 0;
@@ -571,7 +577,7 @@ struct Context {
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
         d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release();
-        h_done.release(); h_kstamp.release(); d_prof.release(); d_flags.release(); d_flevel.release(); d_perm.release(); d_solve_tab.release(); d_dinv.release(); d_bsb_far.release(); d_bsb_flags.release();
+        h_done.release(); h_kstamp.release(); d_prof.release(); d_upd.release(); d_wbuf.release(); d_flags.release(); d_flevel.release(); d_perm.release(); d_solve_tab.release(); d_dinv.release(); d_bsb_far.release(); d_bsb_flags.release();
         if (gexec) (void)hipGraphExecDestroy(gexec);
         gexec = nullptr;
         if (gexec_api) (void)hipGraphExecDestroy(gexec_api);
@@ -671,6 +677,7 @@ constexpr long long INC_POOL_MIN = 8ll << 20;             // doubles (64 MB; the
 static int waves_of(int nt) { return nt >= 1024 ? 16 : (nt >= 512 ? 8 : 4); }
 // workgroup size of k_front_small on a level with n fronts: latency levels take the big workgroup (more lanes on one
 // front's critical path), throughput levels the smaller one (more workgroups per CU)
+static long long g_updstat[6] = { 0 };      // APRILSAM_AMD_INC_PROFILE: general-path steps with / without updated fronts, fronts updated / re-factorised in the former, re-factorised in the latter, steps through k_inc_one
 static double g_incsub[8] = { 0 }; static long long g_incsub_n = 0;      // APRILSAM_AMD_INC_PROFILE: host sub-phases of the general incremental path (ms, summed)
 static const bool g_incprof_stamps = [] { const char *e = getenv("APRILSAM_AMD_INC_PROFILE"); return e && *e == '2'; }();      // (see IncProf)
 static int small_threads_for(size_t n_fronts) { return (int)n_fronts >= g_opt.tp_fronts ? std::min(g_opt.small_threads, g_opt.tp_threads) : g_opt.small_threads; }
@@ -924,7 +931,8 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
         }
     }
     // (dependency flags / front levels: also used by the extended-plan batch step, whose tail fronts get levels of their own)
-    c.d_flags.need((size_t)2 * (P.nF + MAX_TAIL_FRONTS)); c.d_flevel.need((size_t)P.nF + MAX_TAIL_FRONTS);
+    c.d_flags.need((size_t)3 * (P.nF + MAX_TAIL_FRONTS)); c.d_flevel.need((size_t)P.nF + MAX_TAIL_FRONTS);      // done / x done / vectors ready
+    if (inc) { c.d_upd.need((size_t)g_opt.persist_max_fronts + 64); c.d_wbuf.need((size_t)1 << 19); }
     HIPCHECK(hipMemcpyAsync(c.d_flevel.p, P.f_level.data(), (size_t)P.nF * 4, hipMemcpyHostToDevice, s));
     if (tab.empty()) tab.push_back(0);
     c.d_tab.need(tab.size() + INC_TAB_);
@@ -1330,6 +1338,7 @@ static void inc_prepare(Context &c) {        // after a full (re)plan: c.plan is
     I.f_level.assign(P.f_level.begin(), P.f_level.end());
     I.fd.resize(P.nF);
     I.t_first.clear(); I.t_cnt.clear(); I.tf_of.clear(); I.kids.assign(P.nF, {}); I.tail_ok = -1; I.recs_stale = -1;
+    I.stale.assign(P.nF, 0); I.upd_ok = true;
     I.base_levels = c.levels;
     c.inc_slot_blk.clear(); c.inc_slot_rhs.clear();
     I.ready = true;
@@ -1415,7 +1424,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             FrontDesc &D = I.fd[T];
             D.nsb = n_new; D.nub = nph; I.cur_nub[T] = nph;
             I.recs_stale = T; I.tail_ok = T;
-            c.st.reserved0 = 1;
+            c.st.reserved0 = 1; c.st.inc_fronts_updated = 0;
             // patches
             PatchList &PL = c.patches;
             PL.reset();
@@ -1483,19 +1492,21 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     if (!tail_fast && I.recs_stale >= 0) I.dirty[I.recs_stale] = 1;
     // ---- 0. new poses join the last tail front, or open the next one --------------------------------------------------
     auto n_tail = [&]() { return (int)I.t_first.size(); };
+    int grown_lo = 1 << 30;                              // first tail front that gained own poses in this step (several may: a front fills up, the next opens)
     for (int k = std::max(Nold, Nb); k < N; k++) {
         if (I.t_first.empty() || I.t_cnt.back() >= TAIL_POSES) {
             if (n_tail() >= MAX_TAIL_FRONTS - 1) return false;
             I.t_first.push_back(k); I.t_cnt.push_back(0);
             const int t = nF0 + n_tail() - 1;
             I.parent.push_back(-1); I.E.emplace_back(); I.xfac.emplace_back(); I.rel_begin.push_back(0); I.cur_nub.push_back(0); I.cur_cap.push_back(0);
-            I.dirty.push_back(0); I.f_level.push_back(I.nLev0 + n_tail() - 1); I.kids.emplace_back();
+            I.dirty.push_back(0); I.f_level.push_back(I.nLev0 + n_tail() - 1); I.kids.emplace_back(); I.stale.push_back(0);
             I.fd.emplace_back(); memset(&I.fd[t], 0, sizeof(FrontDesc));
             I.fd[t].first = k; I.fd[t].parent = -1; I.fd[t].dinv0 = -1;
         }
         I.t_cnt.back()++;
         I.tf_of.push_back(nF0 + n_tail() - 1);
         I.dirty[nF0 + n_tail() - 1] = 1;                 // its own columns changed
+        grown_lo = std::min(grown_lo, nF0 + n_tail() - 1);
     }
     const int nT = n_tail(), nFr = nF0 + nT;
     auto is_tail = [&](int t) { return t >= nF0; };
@@ -1511,11 +1522,12 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     // tail pose k enters the structure of front t and of every front above it, up to the front that owns k.  Fronts
     // without a base parent hang below the tail front that owns the first tail pose of their structure.
     bool unfit = false;
+    std::vector<char> &mid = I.st_mid; mid.assign(nFr, 0);      // fronts whose structure gained a row that is NOT its last one (their arrays cannot be updated by appending)
     auto add_struct = [&](int t, int k) {
         while (t >= 0 && !owns(t, k)) {
             auto &E = I.E[t];
             auto it = std::lower_bound(E.begin(), E.end(), k);
-            if (it == E.end() || *it != k) { E.insert(it, k); I.dirty[t] = 1; }
+            if (it == E.end() || *it != k) { if (it != E.end()) mid[t] = 1; E.insert(it, k); I.dirty[t] = 1; }
             if (is_tail(t) || P.f_parent[t] < 0) {
                 const int par = I.tf_of[E.front() - Nb];
                 if (I.parent[t] >= 0 && I.parent[t] != par) { unfit = true; return; }     // re-parenting a front with structure: re-plan
@@ -1526,6 +1538,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     };
     const double tsub0 = now_ms();
     // ---- 1. owners of the new factors, tail rows along root paths ----------------------------------------------
+    std::vector<int> &owner_of = I.st_owner; owner_of.assign(F - Fold, -1);
     for (int f = Fold; f < F; f++) {
         const int a = fa[f], b = fb[f];
         const bool ta = a >= Nb, tb = b >= Nb;
@@ -1544,8 +1557,58 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         if (unfit) return false;
         I.xfac[owner].push_back(f);
         I.dirty[owner] = 1;
+        owner_of[f - Fold] = owner;
     }
+    // (a batch step on the extended plan re-assembles EVERY front from its records: the ones update steps bypassed are rebuilt first)
+    if (batch) for (int t = 0; t < nFr; t++) if (I.stale[t]) I.dirty[t] = 1;
     for (int t = 0; t < nFr; t++) if (I.dirty[t] && I.parent[t] >= 0) I.dirty[I.parent[t]] = 1;     // (parents have larger ids)
+    // ---- 1b. which dirty fronts take a low-rank UPDATE of their factor instead of being re-assembled and re-factorised ----------
+    // (front_update_body).  Eligible: the front keeps its own columns (every front but the last tail front), the rows its
+    // structure gained come last, its array is a single-workgroup one, the new factors it owns have a symmetric positive
+    // definite W, and every dirty child is updated too (the vectors a front receives come from its children's updates).
+    std::vector<char> &mode = I.st_mode; mode.assign(nFr, 0);
+    std::vector<int> &fmask = I.st_mask, &fslot = I.st_slot; fmask.assign(nFr, 0); fslot.assign(F - Fold, -1);
+    auto kids_of = [&](int t, const int **kb, const int **ke) {
+        if (t >= nF0) { *kb = I.kids[t].data(); *ke = *kb + I.kids[t].size(); }
+        else { *kb = P.ch_idx.data() + P.ch_ptr[t]; *ke = P.ch_idx.data() + P.ch_ptr[t + 1]; }
+    };
+    bool any_upd = false;
+    if (!batch && g_opt.inc_update && I.upd_ok && !tail_fast && g_opt.persist && g_opt.inc_multi && g_opt.wave_backsolve) {
+        const size_t small_max = (size_t)g_opt.small_lds_kb * 1024;
+        const int nw = waves_of(small_threads_for(1));
+        int n_dirty = 0, n_slots = 0;
+        for (int t = 0; t < nFr; t++) n_dirty += I.dirty[t] ? 1 : 0;
+        for (int t = 0; t < nFr && n_dirty <= g_opt.persist_max_fronts; t++) {
+            if (!I.dirty[t] || t == nFr - 1 || t >= grown_lo || mid[t] || I.cur_cap[t] <= 0) continue;      // (t >= grown_lo: its own columns changed)
+            const int nsb = t >= nF0 ? I.t_cnt[t - nF0] : P.f_nsb[t], nub = (t >= nF0 ? 0 : P.f_nub[t]) + (int)I.E[t].size();
+            const int R = 3 * (nsb + nub + 1);
+            bool ok = small_front_lds(R, R - 3, nw) <= small_max || (g_opt.panel_mode && panel_front_lds(R, 3 * nsb, nw) <= small_max);
+            const int *kb, *ke; kids_of(t, &kb, &ke);
+            int ndc = 0, msk = 0;
+            for (const int *kp = kb; kp != ke && ok; kp++) if (I.dirty[*kp]) { ok = mode[*kp] != 0; msk |= fmask[*kp]; ndc++; }
+            ok = ok && ndc <= UPD_MAXC;
+            int nown = 0;
+            for (size_t q = I.xfac[t].size(); q-- > 0 && ok;) {
+                const int f = I.xfac[t][q];
+                if (f < Fold) break;                   // (the factors of this step are the last ones of the list)
+                // W = C C^T must exist: symmetric, pivots well away from zero (the kernel repeats this factorisation)
+                const double *w = gp.h_W.p + (size_t)9 * f;
+                ok = w[1] == w[3] && w[2] == w[6] && w[5] == w[7] && w[0] > 0;
+                if (ok) {
+                    const double c00 = std::sqrt(w[0]), c10 = w[3] / c00, c20 = w[6] / c00, d1 = w[4] - c10 * c10;
+                    ok = d1 > 1e-12 * w[4];
+                    if (ok) { const double c11 = std::sqrt(d1), c21 = (w[7] - c20 * c10) / c11, d2 = w[8] - c20 * c20 - c21 * c21; ok = d2 > 1e-12 * w[8]; }
+                }
+                nown++;
+            }
+            ok = ok && nown <= UPD_MAXF && n_slots + nown <= UPD_MAXF;
+            if (ok) {
+                for (size_t q = I.xfac[t].size(); q-- > 0;) { const int f = I.xfac[t][q]; if (f < Fold) break; fslot[f - Fold] = n_slots; msk |= 1 << n_slots; n_slots++; }
+                ok = msk != 0 && update_front_lds(R, 3 * nsb, __builtin_popcount(msk)) <= (size_t)160 * 1024;
+            }
+            if (ok) { mode[t] = 1; fmask[t] = msk; any_upd = true; }
+        }
+    }
     const double tsub1 = now_ms();
     // ---- 2. regenerate dirty fronts (children before parents) ----------------------------------------------------
     std::vector<int> &st_i32 = I.st_i32; std::vector<DestRec> &st_dest = I.st_dest; std::vector<ChildRec> &st_child = I.st_child;
@@ -1561,6 +1624,9 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         for (int k = 0; k < 2; k++) new_slot_rhs[(size_t)2 * (f - Fold) + k] = c.inc_slot_rhs[(size_t)2 * (f - I.Fb) + k] = I.slots_used++;
     }
     const long long i32_base = I.i32_used, dest_base = I.dest_used, child_base = I.child_used;
+    std::vector<UpdRec> &rec_of = I.st_rec; std::vector<int> &wout_of = I.st_wout;
+    if (any_upd) { rec_of.resize(nFr); wout_of.assign(nFr, 0); }
+    long long wbuf_used = 0;
     struct Ent { int col, row, f, k, slot; };
     std::vector<Ent> ents;
     auto nsb_of = [&](int t) { return is_tail(t) ? I.t_cnt[t - nF0] : P.f_nsb[t]; };
@@ -1585,9 +1651,13 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             continue;
         }
         if (t == I.recs_stale) I.recs_stale = -1;
-        if (need > I.cur_cap[t]) {
+        const bool upd = any_upd && mode[t];
+        const int old_nub = I.cur_nub[t]; const long long old_off = D.off;
+        // (an updated front whose structure grew is written to a FRESH array in the new layout -- nothing moves in place; one that
+        // keeps its structure is updated where it is)
+        if (upd ? nub != old_nub : need > I.cur_cap[t]) {
             // growing fronts (the last tail front, fronts collecting tail rows) get head-room: no new array every step
-            const int gb = tail ? std::max(nbc + 4, TAIL_POSES + (int)E.size() + 4) : nbc + 4;
+            const int gb = upd ? nbc : tail ? std::max(nbc + 4, TAIL_POSES + (int)E.size() + 4) : nbc + 4;
             const long long want = (long long)(3 * (gb + 1)) * (3 * gb);
             const long long off = (I.pool_used + 31) & ~31ll;
             if (off + want > I.pool_cap) return false;
@@ -1608,6 +1678,39 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             }
             return local_base(t, P.pos[node]);
         };
+        if (upd) {
+            // low-rank update: no destination records, no child records (stale from here on: rebuilt when the front is next
+            // re-assembled); what the kernel needs is where the vectors come from and where its own go
+            UpdRec u; memset(&u, 0, sizeof(u));
+            u.old_off = old_off; u.mode = 1; u.old_nub = old_nub; u.mask = fmask[t];
+            u.wout = (int)wbuf_used; wout_of[t] = u.wout;
+            wbuf_used += (long long)3 * UPD_MAXF * (3 * nub + 1);
+            if (wbuf_used > (long long)c.d_wbuf.cap) return false;
+            for (int f : I.xfac[t]) {
+                if (f < Fold) continue;
+                const int la = local(fa[f]), lb = fb[f] >= 0 ? local(fb[f]) : -1;
+                new_swap[f - Fold] = (lb >= 0 && la < lb);         // (orientation of the off-diagonal block in its contribution slot, for later re-assemblies)
+                u.own_f[u.n_own] = f; u.own_la[u.n_own] = la; u.own_lb[u.n_own] = lb; u.own_slot[u.n_own] = fslot[f - Fold]; u.n_own++;
+            }
+            const int *kb, *ke; kids_of(t, &kb, &ke);
+            for (const int *kp = kb; kp != ke; kp++) {
+                const int ch = *kp;
+                if (!I.dirty[ch]) continue;
+                const std::vector<int> &Ec = I.E[ch];
+                I.rel_begin[ch] = (int)(i32_base + (long long)st_i32.size());
+                if (ch < nF0) st_i32.insert(st_i32.end(), P.f_rel.begin() + P.f_rows_ptr[ch], P.f_rel.begin() + P.f_rows_ptr[ch + 1]);
+                for (int k : Ec) st_i32.push_back(local(k));
+                u.ch_t[u.n_ch] = ch; u.ch_wout[u.n_ch] = wout_of[ch]; u.ch_rel[u.n_ch] = I.rel_begin[ch];
+                u.ch_cnu[u.n_ch] = nub0_of(ch) + (int)Ec.size(); u.ch_mask[u.n_ch] = fmask[ch]; u.n_ch++;
+            }
+            rec_of[t] = u;
+            I.stale[t] = 1;
+            D.parent = I.parent[t];
+            fd_dirty.push_back(t);
+            lev_dirty[I.f_level[t]].push_back(t);
+            continue;
+        }
+        I.stale[t] = 0;
         // destination records: only fronts that own factors added since the batch need new ones
         if (!I.xfac[t].empty()) {
             ents.clear();
@@ -1771,6 +1874,19 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             for (int l = 0; l < nLev; l++) if (!lev_dirty[l].empty()) for (int k = 0; k < dl[l].n_small; k++) tab.push_back(tab[dl[l].small_off - sh + k]);
         }
     }
+    // updated fronts only exist inside that launch (or k_inc_one's loop over the same list): one record per list entry
+    if (any_upd) {
+        if (!iu || (size_t)iu_n > c.d_upd.cap || (size_t)3 * nFr > c.d_flags.cap) return false;      // (the eligibility pass checked what iu checks: a full re-plan otherwise)
+        I.st_upd.resize(iu_n);
+        const int sh = (int)I.tab_used;
+        for (int i = 0; i < iu_n; i++) {
+            const int t = tab[iu_off - sh + i];
+            if (mode[t]) {
+                I.st_upd[i] = rec_of[t];
+                iu_lds = std::max(iu_lds, update_front_lds(3 * (nsb_of(t) + I.cur_nub[t] + 1), 3 * nsb_of(t), __builtin_popcount(fmask[t])));
+            } else memset(&I.st_upd[i], 0, sizeof(UpdRec));
+        }
+    }
     if (id) {
         if (needed) {                                   // the lists of the marked root paths are contiguous, top level first
             id_off = bs_off[nLev - 1];
@@ -1800,15 +1916,22 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     if (one) {
         for (int l = 0; l < nLev; l++) for (int t : lev_dirty[l]) {         // the kernel's own full / panel decision, at its thread count
             const int R = 3 * (nsb_of(t) + I.cur_nub[t] + 1), C = R - 3;
+            if (any_upd && mode[t]) { one_lds = std::max(one_lds, update_front_lds(R, 3 * nsb_of(t), __builtin_popcount(fmask[t]))); continue; }
             const size_t full = small_front_lds(R, C, one_nt / 64);
             one_lds = std::max(one_lds, (long long)full <= iu_full ? full : panel_front_lds(R, 3 * nsb_of(t), one_nt / 64));
         }
         one = one_lds <= 160 * 1024;
     }
-    if (!one) { iu = iu && iu_n >= 2; id = id && id_n >= 2; }
+    if (!one) { iu = iu && (iu_n >= 2 || any_upd); id = id && id_n >= 2; }
     if (tail_fast && !one && tail_refactor_lds() > 64 * 1024) return false;       // (never: the refactorisation alone runs as k_inc_one without lists)
     if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return false;
     c.st.reserved0 = (int)fd_dirty.size();              // fronts regenerated by this step (tools/inc_hist.py)
+    if (!batch) {
+        int nu_ = 0; for (int t : fd_dirty) nu_ += (any_upd && mode[t]) ? 1 : 0;
+        c.st.inc_fronts_updated = nu_;
+        if (any_upd) { g_updstat[0]++; g_updstat[2] += nu_; g_updstat[3] += (long long)fd_dirty.size() - nu_; } else { g_updstat[1]++; g_updstat[4] += (long long)fd_dirty.size(); }
+        if (one) g_updstat[5]++;
+    }
     const double tsub3 = now_ms();
     // ---- 4. uploads: every table update of this step, the new factors and the new states through ONE pinned staging
     //         buffer, scattered by one kernel (k_apply_patches) -- no copy-engine call on the path ---------------------------
@@ -1830,6 +1953,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     PL.add(c.d_tab.p + I.tab_used, tab.data(), tab.size() * 4);
     I.i32_used += (long long)st_i32.size(); I.dest_used += (long long)st_dest.size(); I.child_used += (long long)st_child.size();
     for (int t : fd_dirty) PL.add(c.d_fd.p + t, &I.fd[t], sizeof(FrontDesc));
+    if (any_upd) PL.add(c.d_upd.p, I.st_upd.data(), I.st_upd.size() * sizeof(UpdRec));
     if (F > Fold) {
         PL.add((int *)c.dp.slot_blk + (size_t)3 * Fold, new_slot_blk.data(), new_slot_blk.size() * 4);
         PL.add((int *)c.dp.slot_rhs + (size_t)2 * Fold, new_slot_rhs.data(), new_slot_rhs.size() * 4);
@@ -1859,6 +1983,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     const double tsub4 = now_ms();
     // ---- 5. numeric: new factors linearised, dirty fronts level by level, back substitution, update ----------------------
     set_small_attr();
+    const UpdCtx uctx = any_upd ? UpdCtx{ c.d_upd.p, c.d_wbuf.p, c.d_flags.p + (size_t)2 * nFr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p, gp.d_lp.p, gp.d_state.p } : UpdCtx{};
     if (batch) {
         PL.launch(s);
         hipLaunchKernelGGL(k_load_states, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.d_state.p, gp.d_lp.p);      // l_point <- state
@@ -1898,17 +2023,17 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             }
             gp.h_out.need((size_t)3 * N);
             const UpdArgs upd1{ c.d_perm.p, gp.d_lp.p, nullptr, gp.d_dx.p, gp.h_out.p, gp.h_dx.p, c.h_bad.p };
-            if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
-            else if (one_nt >= 512) hipLaunchKernelGGL(k_inc_one<512>, dim3(1), dim3(512), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
-            else hipLaunchKernelGGL(k_inc_one<256>, dim3(1), dim3(256), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1);
+            if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1, uctx);
+            else if (one_nt >= 512) hipLaunchKernelGGL(k_inc_one<512>, dim3(1), dim3(512), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1, uctx);
+            else hipLaunchKernelGGL(k_inc_one<256>, dim3(1), dim3(256), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1, uctx);
         } else
             hipLaunchKernelGGL(k_inc_prologue, dim3(1), dim3(1024), 0, s, pro, fl, c.inl);
     }
     if (iu && !one) {
         const int *list = c.d_tab.p + iu_off;
-        if (iu_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(iu_n), dim3(1024), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1);
-        else if (iu_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(iu_n), dim3(512), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1);
-        else hipLaunchKernelGGL(k_front_small<256>, dim3(iu_n), dim3(256), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1);
+        if (iu_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(iu_n), dim3(1024), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1, uctx);
+        else if (iu_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(iu_n), dim3(512), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1, uctx);
+        else hipLaunchKernelGGL(k_front_small<256>, dim3(iu_n), dim3(256), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1, uctx);
     }
     for (int l = 0; l < nLev; l++) {
         if (lev_dirty[l].empty() || iu || one) continue;
@@ -2195,6 +2320,8 @@ struct IncProf {
                 g_full_reason[3], g_full_reason[0], g_full_reason[1], g_full_reason[2]);
         if (g_incsub_n) fprintf(stderr, "aprilsam_amd inc profile, general path over %lld steps (us/step): owners %.2f regenerate fronts %.2f launch tables %.2f patches %.2f enqueue %.2f | fronts regenerated per step %.1f | steps eligible for tail_refactor %.0f, of them with a short walk and patched states %.0f\n",
                                 g_incsub_n, 1e3 * g_incsub[0] / g_incsub_n, 1e3 * g_incsub[1] / g_incsub_n, 1e3 * g_incsub[2] / g_incsub_n, 1e3 * g_incsub[3] / g_incsub_n, 1e3 * g_incsub[4] / g_incsub_n, g_incsub[5] / g_incsub_n, g_incsub[6], g_incsub[7]);
+        fprintf(stderr, "aprilsam_amd inc profile, low-rank updates: %lld general-path steps with updated fronts (%lld fronts updated, %lld re-factorised), %lld without (%lld fronts re-factorised); %lld of all of them as one launch\n",
+                g_updstat[0], g_updstat[2], g_updstat[3], g_updstat[1], g_updstat[4], g_updstat[5]);
         if (!kst.empty()) {
             double km[4];
             for (int k = 0; k < 4; k++) {
@@ -2274,6 +2401,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         inc_prepare(c);
     }
     c.inc_F = F; c.inc_N = N; c.same_topo_batches = 0;
+    if (!reused) c.st.inc_fronts_updated = 0;
     c.st.inc_replanned = reused ? 0 : 1; c.st.inc_old_old_cross = c.model.old_old_cross;      // (include/aprilsam_amd.h: what the caller is told)
     const double tp4 = now_ms();
     if (!reused) {                // (the fast path's last kernel wrote states, dx and the pivot flag into the pinned mirrors itself)
@@ -2306,6 +2434,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         static bool warned = false;
         if (!warned) { fprintf(stderr, "aprilsam_amd: incremental system not positive definite; node states left untouched\n"); warned = true; }
         c.inc.tail_ok = -1;                          // (a front stopped half-way: nothing to refactorise from)
+        c.inc.upd_ok = false;                        // (... nor to update)
         return;
     }
     // bookkeeping exactly as the reference: which poses solve_node visits / updates, start_over (refmodel.cpp)
@@ -3355,6 +3484,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "inc_one_spin") g_opt.inc_one_spin = (int)v;
     else if (k == "inc_tail") g_opt.inc_tail = (int)v;
     else if (k == "inc_inline") g_opt.inc_inline = (int)v;
+    else if (k == "inc_update") g_opt.inc_update = (int)v;
     else if (k == "speculate_factors") g_opt.speculate_factors = (int)v;
     else if (k == "block_factor") g_opt.block_factor = (int)v;
     else if (k == "pin_last") g_opt.pin_last = (int)v;
@@ -3373,7 +3503,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "mem_cap_mb") g_opt.mem_cap_mb = (int)v;
     else return -1;
     // host-side policies that no launch table or captured graph depends on
-    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "inc_multi", "inc_one", "inc_one_up", "inc_one_dn", "inc_one_threads", "inc_one_spin", "inc_inline", "speculate_factors", "batch_extend",
+    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "inc_multi", "inc_one", "inc_one_up", "inc_one_dn", "inc_one_threads", "inc_one_spin", "inc_inline", "inc_update", "speculate_factors", "batch_extend",
                                              "extend_tail_fronts", "mem_cap_mb", "medium_lds_kb" };
     bool policy = false;
     for (const char *q : no_replan) policy = policy || k == q;

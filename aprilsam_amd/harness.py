@@ -64,7 +64,7 @@ def run_tutorial(lib, batch_update_only=False, nthreshold=100, delta_xy=0.1, del
 
 
 def run_demo(lib, arrays, batch_update_only=False, nthreshold=100, delta_xy=0.1, delta_theta=0.1,
-             max_poses=None, deterministic=True, record_states_every=0):
+             max_poses=None, deterministic=True, record_states_every=0, on_step=None):
     """arrays = (states, fa, fb, z, W) of the LOADED graph (no prior). Returns dict with per-step chi2, ms,
     batch fall-back flags and the final states."""
     states, fa, fb, z, W = arrays
@@ -102,6 +102,8 @@ def run_demo(lib, arrays, batch_update_only=False, nthreshold=100, delta_xy=0.1,
             g.cholesky_inc(p)
             was_batch[k] = p.c.batch_time != bt         # a fall-back batch rewrites batch_time
         ms[k] = (time.perf_counter() - t0) * 1e3
+        if on_step is not None:
+            on_step(k, p, bool(was_batch[k]))
         chi2[k] = g.chi2()
         if record_states_every and (k % record_states_every == 0 or k == N - 1):
             snaps[k] = g.states()

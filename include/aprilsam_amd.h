@@ -226,7 +226,10 @@ typedef struct aprilsam_amd_stats {
                                   branches of the reference's elimination tree.  For those the reference's partial re-factorisation
                                   (aprilsam.c:850-906, children first over the OLD tree) finalises one row before the other has updated it and
                                   returns something that is NOT the solution of its own normal equations; this library returns the exact solve
-                                  (INTEGRATION.md section 6).  > 0 therefore means: this step's states deviate from the reference's by design */
+                                  (INTEGRATION.md section 4).  > 0 therefore means: this step's states deviate from the reference's by design */
+    int    inc_fronts_updated; /* fronts whose factor took a low-rank update in this step (option "inc_update") instead of being re-assembled and
+                                  re-factorised; reserved0 counts all fronts the step regenerated */
+    int    reserved2;
 } aprilsam_amd_stats_t;
 int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_amd_stats_t *out);
 

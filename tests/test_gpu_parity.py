@@ -289,6 +289,8 @@ def test_incremental_demo_matches_reference_schedule(lib, inc_fast):
     {"inc_one_threads": 1024}, {"inc_one_threads": 256},
     {"inc_one_up": 1, "inc_one_dn": 1},               # k_inc_one for single-front steps only
     {"tail_poses": 8},                                # short tail fronts: new tail fronts open often
+    {"inc_update": 0},                                # loop closures re-assemble and re-factorise their root paths (no low-rank updates)
+    {"inc_update": 1, "inc_one_up": 16, "inc_one_dn": 16},   # low-rank updates inside k_inc_one (front after front in one workgroup) wherever the walk is short
 ], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
 def test_incremental_step_launch_forms_agree_with_the_reference_golden(lib, opts):
     """The launch forms of an incremental step (k_inc_one with tail_refactor, k_inc_one with regenerated fronts, multi-level
@@ -297,7 +299,7 @@ def test_incremental_step_launch_forms_agree_with_the_reference_golden(lib, opts
     G = golden("m3500_inc_demo.npz")
     n = 420
     defaults = {"inc_tail": 1, "inc_one": 1, "inc_multi": 1, "inc_inline": 1, "inc_one_spin": 1, "inc_one_threads": 512,
-                "inc_one_up": 3, "inc_one_dn": 4, "tail_poses": 28}
+                "inc_one_up": 3, "inc_one_dn": 4, "tail_poses": 28, "inc_update": 1}
     for k, v in opts.items():
         lib.set_option(k, v)
     try:
@@ -308,6 +310,39 @@ def test_incremental_step_launch_forms_agree_with_the_reference_golden(lib, opts
     assert np.array_equal(res["was_batch"], G["was_batch"][:n])
     rel = np.abs(res["chi2"] - G["chi2"][:n]) / np.maximum(G["chi2"][:n], 1e-9)
     assert np.max(rel) < CHI2_RTOL, (int(np.argmax(rel)), float(np.max(rel)))
+
+
+def test_loop_closures_take_low_rank_updates_and_match_the_golden(lib):
+    """Round 4: the fronts on a loop closure's root path are UPDATED (front_update_body: three vectors per new factor travelling
+    up the assembly tree), not re-assembled and re-factorised.  The first 700 poses of the demo: most fronts regenerated by
+    loop-closure steps must have taken the update (stats.inc_fronts_updated), with the identical fall-back schedule and
+    chi^2 within 1e-6 of the reference golden at every step; with the option off nothing is updated and the numbers agree."""
+    G = golden("m3500_inc_demo.npz")
+    n = 700
+    out = {}
+    for upd in (1, 0):
+        lib.set_option("inc_update", upd)
+        regen, updated = [], []
+
+        def on_step(k, p, was_batch):
+            if k and not was_batch:
+                st = p.stats()
+                if st["symbolic_reused"]:
+                    regen.append(st["reserved0"]); updated.append(st["inc_fronts_updated"])
+        try:
+            res = harness.run_demo(lib, datasets.m3500_arrays(), max_poses=n, deterministic=True, on_step=on_step)
+        finally:
+            lib.set_option("inc_update", 1)
+        assert np.array_equal(res["was_batch"], G["was_batch"][:n])
+        rel = np.abs(res["chi2"] - G["chi2"][:n]) / np.maximum(G["chi2"][:n], 1e-9)
+        assert np.max(rel) < CHI2_RTOL, (upd, int(np.argmax(rel)), float(np.max(rel)))
+        out[upd] = (np.array(regen), np.array(updated), res["chi2"])
+    regen, updated, c1 = out[1]
+    multi = regen >= 2                                    # steps that touched more than the last tail front
+    assert multi.sum() > 100 and updated[multi].sum() >= 0.7 * (regen[multi] - 1).sum(), (int(multi.sum()), int(updated.sum()), int(regen[multi].sum()))
+    assert np.all(updated <= np.maximum(regen - 1, 0))    # (the last tail front is always re-factorised)
+    assert out[0][1].sum() == 0
+    assert np.max(np.abs(c1 - out[0][2]) / np.maximum(out[0][2], 1e-9)) < 1e-9
 
 
 def test_incremental_general_usage_falls_back_to_replanning(lib, oracle):
