@@ -18,6 +18,8 @@ struct Options {
     int inc_one_up = 3, inc_one_dn = 4, inc_one_threads = 512, inc_one_spin = 1;
     int inc_tail = 1;             // ... and steps whose factors touch the last few poses of the last tail front alone re-factorise its trailing columns only
     int inc_inline = 1;           // ... a small step's table / factor / state patches travel in the kernel arguments instead of being read across PCIe
+    int inc_tail_solve = 1;       // ... and when every pose the step's walk visits lies among those trailing columns, the back substitution and the state update happen in the same LDS window
+    int inc_lazy_states = 1;      // ... and a step whose walk is partial compares only the node objects it reads (poses of its new factors, visited poses) with the state mirrors, not all of them
     int inc_update = 1;           // ... and the fronts on the root path of a loop closure take a low-rank UPDATE of their factor (front_update_body) instead of being re-assembled and re-factorised
     int speculate_factors = 1;    // warm batch calls: the pass over the factor objects (edits in place) runs under the GPU's work on the packed copies; an edit voids the run
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)

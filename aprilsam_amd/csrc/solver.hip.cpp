@@ -78,6 +78,8 @@ static void load_env_options() {
         v = g_opt.inc_tail; envd("APRILSAM_AMD_INC_TAIL", &v); g_opt.inc_tail = (int)v;
         v = g_opt.inc_inline; envd("APRILSAM_AMD_INC_INLINE", &v); g_opt.inc_inline = (int)v;
         v = g_opt.inc_update; envd("APRILSAM_AMD_INC_UPDATE", &v); g_opt.inc_update = (int)v;
+        v = g_opt.inc_tail_solve; envd("APRILSAM_AMD_INC_TAIL_SOLVE", &v); g_opt.inc_tail_solve = (int)v;
+        v = g_opt.inc_lazy_states; envd("APRILSAM_AMD_INC_LAZY_STATES", &v); g_opt.inc_lazy_states = (int)v;
         v = g_opt.speculate_factors; envd("APRILSAM_AMD_SPECULATE_FACTORS", &v); g_opt.speculate_factors = (int)v;
         v = g_opt.block_factor; envd("APRILSAM_AMD_BLOCK_FACTOR", &v); g_opt.block_factor = (int)v;
         v = g_opt.fused_panel; envd("APRILSAM_AMD_FUSED_PANEL", &v); g_opt.fused_panel = (int)v;
@@ -253,7 +255,9 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_ol
     const int N = zsize(g->nodes);
     int from = gp.F;
     bool valid = from <= F && (int)gp.fptr.size() == from;
-    if (valid && trust) valid = from == 0 || memcmp(gp.fptr.data(), fs, sizeof(void *) * from) == 0;
+    // (incremental calls only ever look at the factors added since the previous call, aprilsam.c:508-511: first and last packed pointer
+    // as a sanity check instead of all of them -- the comparison of 5 000 pointers was a microsecond of every step)
+    if (valid && trust) valid = from == 0 || (validate_old ? memcmp(gp.fptr.data(), fs, sizeof(void *) * from) == 0 : (gp.fptr[0] == fs[0] && gp.fptr[from - 1] == fs[from - 1]));
     if (!valid) { from = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; gp.is_host.clear(); }
     gp.h_fa.need(F, true); gp.h_fb.need(F, true); gp.h_z.need((size_t)3 * F, true); gp.h_W.need((size_t)9 * F, true);
     gp.fptr.resize(F); gp.is_host.resize(F, 0);
@@ -440,6 +444,40 @@ static bool pack_states_diff(GraphPack &gp, const april_graph_t *g) {
     return !full;
 }
 
+// The same for a step whose walk visits only a few poses (aprilsam.c:755-771, naffected <= 5): what the step READS are the
+// l_points / states of the poses of its new factors and of the poses it visits, plus the new poses -- only those are compared
+// with the mirrors and patched.  The cost of a step then no longer grows with the size of the graph (the full walk is 1 ns per
+// pose per step: 3.5 us on M3500, 100 us on a 100 k-pose graph).  Invariant kept: device arrays == mirrors for EVERY pose;
+// mirror == host object only for the poses some call has looked at since -- every consumer that needs all of them (batch
+// steps, chi^2, full walks, re-plans) walks all node objects itself.
+static bool pack_states_some(GraphPack &gp, const april_graph_t *g, const std::vector<int> &involved) {
+    const int N = zsize(g->nodes);
+    april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
+    if (!gp.mirror_sync || (size_t)3 * N > gp.d_state.cap || (size_t)3 * N > gp.d_lp.cap || (size_t)3 * N > gp.d_dx.cap || (size_t)3 * N > gp.h_state.cap ||
+        (size_t)3 * N > gp.h_lp.cap || (size_t)3 * N > gp.h_dx.cap || (size_t)3 * N > gp.h_out.cap || N < gp.N) return pack_states_diff(gp, g);
+    gp.changed.clear();
+    auto look = [&](int i, bool is_new) {
+        const april_graph_node_t *n = ns[i];
+        if (n->type != APRIL_GRAPH_NODE_XYT_TYPE || n->length != 3) fail(ERR_UNSUPPORTED, "node %d: only xyt nodes (type 100, 3 DoF) are supported (aprilsam.h:94)", i);
+        double *ms = gp.h_state.p + (size_t)3 * i, *ml = gp.h_lp.p + (size_t)3 * i;
+        if (is_new || memcmp(ms, n->state, 24) != 0 || memcmp(ml, n->l_point, 24) != 0) {
+            memcpy(ms, n->state, 24); memcpy(ml, n->l_point, 24);
+            if (std::find(gp.changed.begin(), gp.changed.end(), i) == gp.changed.end()) gp.changed.push_back(i);
+        }
+    };
+    for (int i = gp.N; i < N; i++) look(i, true);
+    const int Nold = gp.N;
+    for (int i : involved) if (i >= 0 && i < Nold) look(i, false);
+    gp.N = N;
+    g_full_reason[3]++;
+    bool full = false;
+    if (gp.pending.size() > 48) { full = true; g_full_reason[1]++; }
+    else for (int i : gp.pending) if (i < N && std::find(gp.changed.begin(), gp.changed.end(), i) == gp.changed.end()) gp.changed.push_back(i);
+    gp.pending.clear();
+    if (!full && gp.changed.size() > 48) { full = true; g_full_reason[2]++; }
+    return !full;
+}
+
 // evaluation points of the unary factors [from, to): the node's state as packed by this call (april_graph_xytpos.c:83-85
 // reads node->state when the factor is evaluated, and the reference evaluates a factor exactly once between batch steps)
 static void record_unary_points(GraphPack &gp, int from, int to, const double *states) {
@@ -544,7 +582,7 @@ struct Context {
     int batch_nodes = 0;                  // #nodes at the last batch step (those carry the Tikhonov term)
     IncState inc;
     int inc_F = 0, inc_N = 0;                      // factors / nodes folded into the factorisation so far
-    std::vector<RefModel::Visit> visits;
+    std::vector<RefModel::Visit> visits; std::vector<int> involved;
     std::vector<int> base_tab;                     // host copy of the launch tables of the base plan
     std::vector<int> inc_slot_blk, inc_slot_rhs;   // slots of the factors added since the base plan (3 / 2 per factor)
     RefModel model;                       // the reference's tree / counters (refmodel.cpp), rebuilt lazily after a batch
@@ -1402,8 +1440,19 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             int t = v.node >= first ? T : (v.node >= Nb ? I.tf_of[v.node - Nb] : I.pos_front[P.pos[v.node]]);
             while (t >= 0 && !I.need[t]) { I.need[t] = 1; lst.push_back(t); t = I.parent[t]; }
         }
+        // every visited pose inside the window of trailing columns the kernel holds in LDS anyway (widened to the first visited
+        // pose): the back substitution and the state update happen right there (tail_refactor, ts.solve) -- no pass over the
+        // whole front, no front list
+        bool solve_here = false;
+        if (g_opt.inc_tail_solve && !needed->empty() && g_opt.inc_one_threads < 1024) {
+            int v_lo = 1 << 30;
+            for (const RefModel::Visit &v : *needed) v_lo = std::min(v_lo, v.node);
+            const int lo_all = std::min(first + tstep.a_idx, v_lo);
+            if (v_lo >= first && n_new - (lo_all - first) <= TAILK) { solve_here = true; tstep.s_idx = lo_all - first; tstep.solve = 1; lst.clear(); lst.push_back(T); }
+        }
         fits = !lst.empty() && (int)lst.size() <= g_opt.inc_one_dn;
-        if (fits) {
+        if (fits && solve_here) fits = (size_t)9 * (I.slots_used + 5 * (F - Fold)) <= c.d_H.cap && (size_t)N <= c.d_perm.cap;
+        else if (fits) {
             std::sort(lst.begin(), lst.end(), [&](int x, int y) { return I.f_level[x] != I.f_level[y] ? I.f_level[x] > I.f_level[y] : x < y; });
             for (int t : lst) { lds = std::max(lds, backsolve_lds(3 * (nsb_now(t) + nub_now(t)), 3 * nsb_now(t), true)); maxns = std::max(maxns, 3 * nsb_now(t)); }
             fits = lds <= 160 * 1024 && maxns <= BSW_MAX_NS && I.tab_used + (long long)lst.size() <= (long long)c.d_tab.cap &&
@@ -1435,7 +1484,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
                 PL.add(gp.d_W.p + (size_t)9 * f0, gp.h_W.p + (size_t)9 * f0, (size_t)(F - f0) * 72);
                 gp.F_on_device = F;
             }
-            PL.add(c.d_tab.p + I.tab_used, lst.data(), lst.size() * 4);
+            if (!solve_here) PL.add(c.d_tab.p + I.tab_used, lst.data(), lst.size() * 4);
             PL.add(c.d_fd.p + T, &D, sizeof(FrontDesc));
             PL.add((int *)c.dp.slot_blk + (size_t)3 * Fold, new_slot_blk.data(), new_slot_blk.size() * 4);
             PL.add((int *)c.dp.slot_rhs + (size_t)2 * Fold, new_slot_rhs.data(), new_slot_rhs.size() * 4);
@@ -1473,7 +1522,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             gp.h_out.need((size_t)3 * N);
             const UpdArgs upd1{ c.d_perm.p, gp.d_lp.p, nullptr, gp.d_dx.p, gp.h_out.p, gp.h_dx.p, c.h_bad.p };
             const IncFlags nofl{ nullptr, 0, nullptr, 0, nullptr, 0 };
-            const int *dn = c.d_tab.p + I.tab_used; const int n_dn = (int)lst.size();
+            const int *dn = c.d_tab.p + I.tab_used; const int n_dn = solve_here ? 0 : (int)lst.size();
             const int one_nt = g_opt.inc_one_threads >= 1024 ? 1024 : g_opt.inc_one_threads >= 512 ? 512 : 256;
             if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, g_opt.block_factor, c.d_x.p, upd1);
             else if (one_nt >= 512) hipLaunchKernelGGL(k_inc_one<512>, dim3(1), dim3(512), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, g_opt.block_factor, c.d_x.p, upd1);
@@ -1487,6 +1536,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             c.st.n_fronts = nFr0; c.st.n_levels = I.nLev0 + nT0;
             return true;
         }
+        tstep.solve = 0; tstep.s_idx = 0;                 // (the general path below runs the back substitution in launches of its own)
     }
     // (any other way of factorising that front reads its destination records: they are brought up to date first)
     if (!tail_fast && I.recs_stale >= 0) I.dirty[I.recs_stale] = 1;
@@ -2365,13 +2415,26 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     c.want_inc = true; c.used_inc = true;
     const double t0 = now_ms();
     pack_factors(gp, g, false);
-    const bool patch_states = pack_states_diff(gp, g);      // pinned mirrors; the fast path patches / loads them from its first kernels
-    const int N = gp.N, F = gp.F;
+    const int N = zsize(g->nodes), F = gp.F;
     c.h_bad.need(4);
-    const double tp1 = now_ms();
+    const double tp0a = now_ms();
     if (!c.model.valid) c.model.batch(c.batch_nodes, c.batch_factors, gp.h_fa.p, gp.h_fb.p);      // lazily, after a batch step
     c.model.inc_begin(N, F, gp.h_fa.p, gp.h_fb.p);
-    const double tp2 = now_ms();
+    std::vector<RefModel::Visit> &visits = c.visits;
+    c.model.plan_visit(visits);                      // structural: which poses the reference's solve_node touches
+    const bool partial = c.model.naffected <= 5;     // aprilsam.c:755: otherwise the whole tree is walked
+    const double tp0b = now_ms();
+    // states: the pinned mirrors follow the node objects; the fast path patches / loads the device copies from its first kernels.
+    // A partial walk reads only the poses of the new factors and the visited ones: only those are looked at (pack_states_some)
+    bool lazy_states = false, patch_states;
+    if (partial && g_opt.inc_lazy_states) {
+        std::vector<int> &inv = c.involved; inv.clear();
+        for (int f = c.inc_F; f < F; f++) { inv.push_back(gp.h_fa.p[f]); if (gp.h_fb.p[f] >= 0) inv.push_back(gp.h_fb.p[f]); }
+        for (const RefModel::Visit &v : visits) inv.push_back(v.node);
+        patch_states = pack_states_some(gp, g, inv); lazy_states = true;
+    } else patch_states = pack_states_diff(gp, g);
+    const double tp1 = now_ms() - (tp0b - tp0a);      // (profile: "pack" = factors + states, "model" = the bookkeeping in between)
+    const double tp2 = tp1 + (tp0b - tp0a);
     if (F > gp.F_cap || !g_opt.inc_fast || !gp.host_idx.empty()) upload_factors(gp);     // (growing the device arrays re-uploads everything)
     if (!gp.host_idx.empty()) {       // new foreign factors are linearised now, at the host objects' current l_points
         eval_host_factors(gp, g, gp.host_evaluated);     // (aprilsam.c:508-542); older ones keep their evaluation
@@ -2380,12 +2443,11 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     const double tp3 = now_ms();
     record_unary_points(gp, c.inc_F, F, gp.h_state.p);  // priors added by this call are evaluated at their node's state now
     // fast path: frozen base plan + TAIL front, only the dirty root paths are regenerated and re-factorised
-    std::vector<RefModel::Visit> &visits = c.visits;
-    c.model.plan_visit(visits);                      // structural: which poses the reference's solve_node touches
-    const bool partial = c.model.naffected <= 5;     // aprilsam.c:755: otherwise the whole tree is walked
+    const int N_before = c.inc_N;
     c.h_bad.p[0] = c.h_bad.p[1] = c.h_bad.p[2] = c.h_bad.p[3] = 0;      // (the riding state update only ever writes a SET failure record)
     bool reused = g_opt.inc_fast && gp.host_idx.empty() && inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, partial ? &visits : nullptr, -1.0, patch_states);
     if (!reused) {                // the step does not fit the frozen structure (or slack ran out): full re-plan
+        if (lazy_states) pack_states(gp, g, true, false);       // (every pose's state / l_point goes to the device below: look at all of them)
         gp.mirror_sync = false; gp.new_states = gp.h_state.p;
         upload_factors(gp);
         HIPCHECK(hipMemcpyAsync(gp.d_state.p, gp.h_state.p, (size_t)24 * N, hipMemcpyHostToDevice, gp.stream));
@@ -2439,7 +2501,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     }
     // bookkeeping exactly as the reference: which poses solve_node visits / updates, start_over (refmodel.cpp)
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
-    for (int i = 0; i < N; i++) ns[i]->UID = i;                          // aprilsam.c:474
+    for (int i = (partial && reused) ? std::min(N_before, N) : 0; i < N; i++) ns[i]->UID = i;      // aprilsam.c:474 (the new nodes; every node where the walk is full anyway)
     const int start_over_before = c.model.start_over;
     apply_visits(c, gp, g, param, N);
     if (param->ordering) free(param->ordering);
@@ -2525,7 +2587,13 @@ static void apply_visits(Context &c, GraphPack &gp, april_graph_t *g, april_grap
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
     const double *x = gp.h_dx.p;                                          // dx per node; NaN where the solve produced NaN
     c.model.count_relinearized(x, param->delta_xy, param->delta_theta, c.visits);
-    for (const RefModel::Visit &vis : c.visits) {
+    const size_t nvis = c.visits.size();
+    for (size_t vk = 0; vk < nvis; vk++) {
+        // (a full walk visits the poses in tree order, i.e. all over the node array: the node object 16 visits ahead and the
+        // arrays behind the one 8 ahead are requested now -- three dependent cache misses per pose otherwise)
+        if (vk + 16 < nvis) __builtin_prefetch(ns[c.visits[vk + 16].node]);
+        if (vk + 8 < nvis) { const april_graph_node_t *n8 = ns[c.visits[vk + 8].node]; __builtin_prefetch(n8->delta_X, 1); __builtin_prefetch(n8->state, 1); }
+        const RefModel::Visit &vis = c.visits[vk];
         const int n = vis.node; const bool update = vis.update;
         april_graph_node_t *nd = ns[n];
         const double *dx = x + (size_t)3 * n;
@@ -3485,6 +3553,8 @@ int api_set_option(const char *name, double v) {
     else if (k == "inc_tail") g_opt.inc_tail = (int)v;
     else if (k == "inc_inline") g_opt.inc_inline = (int)v;
     else if (k == "inc_update") g_opt.inc_update = (int)v;
+    else if (k == "inc_tail_solve") g_opt.inc_tail_solve = (int)v;
+    else if (k == "inc_lazy_states") g_opt.inc_lazy_states = (int)v;
     else if (k == "speculate_factors") g_opt.speculate_factors = (int)v;
     else if (k == "block_factor") g_opt.block_factor = (int)v;
     else if (k == "pin_last") g_opt.pin_last = (int)v;
@@ -3503,7 +3573,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "mem_cap_mb") g_opt.mem_cap_mb = (int)v;
     else return -1;
     // host-side policies that no launch table or captured graph depends on
-    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "inc_multi", "inc_one", "inc_one_up", "inc_one_dn", "inc_one_threads", "inc_one_spin", "inc_inline", "inc_update", "speculate_factors", "batch_extend",
+    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "inc_multi", "inc_one", "inc_one_up", "inc_one_dn", "inc_one_threads", "inc_one_spin", "inc_inline", "inc_update", "inc_tail_solve", "inc_lazy_states", "speculate_factors", "batch_extend",
                                              "extend_tail_fronts", "mem_cap_mb", "medium_lds_kb" };
     bool policy = false;
     for (const char *q : no_replan) policy = policy || k == q;
