@@ -20,6 +20,7 @@ struct Options {
     int inc_inline = 1;           // ... a small step's table / factor / state patches travel in the kernel arguments instead of being read across PCIe
     int inc_tail_solve = 1;       // ... and when every pose the step's walk visits lies among those trailing columns, the back substitution and the state update happen in the same LDS window
     int inc_lazy_states = 1;      // ... and a step whose walk is partial compares only the node objects it reads (poses of its new factors, visited poses) with the state mirrors, not all of them
+    int inc_replan_tall = 1;      // ... and when a front of an all-single-workgroup plan outgrows the LDS (rows collected from loop closures), the step re-plans instead of taking the multi-launch path from then on
     int inc_update = 1;           // ... and the fronts on the root path of a loop closure take a low-rank UPDATE of their factor (front_update_body) instead of being re-assembled and re-factorised
     int speculate_factors = 1;    // warm batch calls: the pass over the factor objects (edits in place) runs under the GPU's work on the packed copies; an edit voids the run
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
@@ -30,7 +31,7 @@ struct Options {
     int lookahead = 0;            // 1: wide trailing updates split, next outer block columns first, the rest on a side stream (measured: no gain)
     int pin_last = 0;             // nested dissection keeps the pin_last newest poses out of the dissection: they form the root front ("recent poses last")
     int batch_extend = 1;         // batch calls on a graph that only grew reuse the plan: appended poses become tail fronts, every front is re-factorised
-    int extend_tail_fronts = 8;   // ... until the tail has this many fronts (then: full re-plan)
+    int extend_tail_fronts = 3;   // ... until the appended poses are this many tail fronts' worth, units of 24 poses (then: full re-plan).  Measured, round 4: demo --batch_update_only 1 500 poses 481 / 388 / 372 / 371 ms at 8 / 4 / 3 / 2; the incremental demo does not care (510 +- 3 %)
     int persist = 1;              // batch path: the top levels of the tree (few small fronts each) as ONE launch per sweep, fronts synchronised by dependency flags
     int persist_max_fronts = 240; // ... as many top levels as fit this many fronts
     int block_panels = 1;         // big fronts: the four panel steps of a 128-column outer block as two launches (diagonal block in LDS, row solves on the matrix cores)

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -80,6 +81,7 @@ static void load_env_options() {
         v = g_opt.inc_update; envd("APRILSAM_AMD_INC_UPDATE", &v); g_opt.inc_update = (int)v;
         v = g_opt.inc_tail_solve; envd("APRILSAM_AMD_INC_TAIL_SOLVE", &v); g_opt.inc_tail_solve = (int)v;
         v = g_opt.inc_lazy_states; envd("APRILSAM_AMD_INC_LAZY_STATES", &v); g_opt.inc_lazy_states = (int)v;
+        v = g_opt.inc_replan_tall; envd("APRILSAM_AMD_INC_REPLAN_TALL", &v); g_opt.inc_replan_tall = (int)v;
         v = g_opt.speculate_factors; envd("APRILSAM_AMD_SPECULATE_FACTORS", &v); g_opt.speculate_factors = (int)v;
         v = g_opt.block_factor; envd("APRILSAM_AMD_BLOCK_FACTOR", &v); g_opt.block_factor = (int)v;
         v = g_opt.fused_panel; envd("APRILSAM_AMD_FUSED_PANEL", &v); g_opt.fused_panel = (int)v;
@@ -542,6 +544,7 @@ struct IncState {
     // low-rank updates of the fronts on a loop closure's root path (front_update_body, option inc_update)
     std::vector<char> stale;                // per front: its destination / child records on the device lack what update steps folded in directly
     bool upd_ok = true;                     // false after a step that failed half-way, until the next full plan
+    bool base_has_big = false;              // the base plan has fronts on the multi-workgroup path
     std::vector<char> st_mid, st_mode; std::vector<int> st_owner, st_mask, st_wout, st_slot; std::vector<UpdRec> st_upd, st_rec;
 };
 
@@ -715,6 +718,8 @@ constexpr long long INC_POOL_MIN = 8ll << 20;             // doubles (64 MB; the
 static int waves_of(int nt) { return nt >= 1024 ? 16 : (nt >= 512 ? 8 : 4); }
 // workgroup size of k_front_small on a level with n fronts: latency levels take the big workgroup (more lanes on one
 // front's critical path), throughput levels the smaller one (more workgroups per CU)
+static long long g_incfail[32] = { 0 };        // APRILSAM_AMD_INC_PROFILE: why inc_fast_step handed a step to a full re-plan (exit number in source order)
+static bool inc_fail(int why) { g_incfail[why & 31]++; return false; }
 static long long g_updstat[6] = { 0 };      // APRILSAM_AMD_INC_PROFILE: general-path steps with / without updated fronts, fronts updated / re-factorised in the former, re-factorised in the latter, steps through k_inc_one
 static double g_incsub[8] = { 0 }; static long long g_incsub_n = 0;      // APRILSAM_AMD_INC_PROFILE: host sub-phases of the general incremental path (ms, summed)
 static const bool g_incprof_stamps = [] { const char *e = getenv("APRILSAM_AMD_INC_PROFILE"); return e && *e == '2'; }();      // (see IncProf)
@@ -989,7 +994,13 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.inc.slots_used = P.n_slots;
     c.inc.ready = false; c.inc.t_first.clear(); c.same_topo_batches = 0;
     c.d_bad.need(4); c.h_bad.need(4);
-    { size_t mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, diag_doubles(c.levels[l].n_big, c.levels[l].n_diag_slots)); c.d_diag.need(mx); }
+    {   // (a param that is used incrementally: fronts near the root collect the rows of every loop closure since the plan was made and
+        // may outgrow the single-workgroup kernel -- room for a few of them on the multi-workgroup path, whose scratch a plan without
+        // such fronts would not have; measured on the M3500 demo: 13 steps re-planned for 70 KB of scratch)
+        size_t mx = inc ? diag_doubles(16, 512) : 1;
+        for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, diag_doubles(c.levels[l].n_big, c.levels[l].n_diag_slots));
+        c.d_diag.need(mx);
+    }
     c.st.n_fronts = P.nF; c.st.n_levels = P.nLevels; c.st.max_front_rows = P.max_rows;
     c.st.nnz_L = P.nnzL; c.st.flops_factor = P.flops; c.st.bytes_fronts = 8.0 * (double)pool_doubles;
 }
@@ -1377,6 +1388,8 @@ static void inc_prepare(Context &c) {        // after a full (re)plan: c.plan is
     I.fd.resize(P.nF);
     I.t_first.clear(); I.t_cnt.clear(); I.tf_of.clear(); I.kids.assign(P.nF, {}); I.tail_ok = -1; I.recs_stale = -1;
     I.stale.assign(P.nF, 0); I.upd_ok = true;
+    I.base_has_big = false;
+    for (const LevelPlan &L : c.levels) I.base_has_big = I.base_has_big || L.n_big > 0;
     I.base_levels = c.levels;
     c.inc_slot_blk.clear(); c.inc_slot_rhs.clear();
     I.ready = true;
@@ -1392,12 +1405,12 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
                           bool patch_states = false) {
     IncState &I = c.inc; Plan &P = c.plan;
     const bool batch = batch_lambda >= 0;
-    if (!I.ready || N < I.Nb || Fold < I.Fb) return false;
+    if (!I.ready || N < I.Nb || Fold < I.Fb) return inc_fail(1);
     // an option that launch tables, front layouts (tail_poses: the padded shape of the last tail front) or captured graphs depend
     // on changed since this plan was made: the frozen base + tail structures were built under the old values -- full re-plan
-    if (c.plan_persist != launch_table_key()) return false;
+    if (c.plan_persist != launch_table_key()) return inc_fail(2);
     const int Nb = I.Nb, nF0 = I.nF0, m = N - Nb;
-    if (m > I.cap_nodes - 8 || F - I.Fb > I.cap_fact - 8 || m < 1) return false;
+    if (m > I.cap_nodes - 8 || F - I.Fb > I.cap_fact - 8 || m < 1) return inc_fail(3);
     const int *fa = gp.h_fa.p, *fb = gp.h_fb.p;
     hipStream_t s = gp.stream;
     auto local_base = [&](int t, int p) -> int {      // local block index of base position p in base front t, or -1
@@ -1545,7 +1558,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     int grown_lo = 1 << 30;                              // first tail front that gained own poses in this step (several may: a front fills up, the next opens)
     for (int k = std::max(Nold, Nb); k < N; k++) {
         if (I.t_first.empty() || I.t_cnt.back() >= TAIL_POSES) {
-            if (n_tail() >= MAX_TAIL_FRONTS - 1) return false;
+            if (n_tail() >= MAX_TAIL_FRONTS - 1) return inc_fail(4);
             I.t_first.push_back(k); I.t_cnt.push_back(0);
             const int t = nF0 + n_tail() - 1;
             I.parent.push_back(-1); I.E.emplace_back(); I.xfac.emplace_back(); I.rel_begin.push_back(0); I.cur_nub.push_back(0); I.cur_cap.push_back(0);
@@ -1602,9 +1615,9 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         } else {
             const int pa = P.pos[a], pb = P.pos[b];
             owner = I.pos_front[std::min(pa, pb)];
-            if (local_base(owner, std::max(pa, pb)) < 0) return false;       // would change the frozen structure
+            if (local_base(owner, std::max(pa, pb)) < 0) return inc_fail(5);       // would change the frozen structure
         }
-        if (unfit) return false;
+        if (unfit) return inc_fail(6);
         I.xfac[owner].push_back(f);
         I.dirty[owner] = 1;
         owner_of[f - Fold] = owner;
@@ -1623,12 +1636,31 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         else { *kb = P.ch_idx.data() + P.ch_ptr[t]; *ke = P.ch_idx.data() + P.ch_ptr[t + 1]; }
     };
     bool any_upd = false;
+    int n_dirty = 0;
+    bool all_small = true;                             // every dirty front still fits the single-workgroup kernel
+    {
+        const size_t small_max = (size_t)g_opt.small_lds_kb * 1024;
+        const int nw = waves_of(small_threads_for(1));
+        for (int t = 0; t < nFr; t++) {
+            if (!I.dirty[t]) continue;
+            n_dirty++;
+            const int nsb = t >= nF0 ? I.t_cnt[t - nF0] : P.f_nsb[t];
+            int nub = (t >= nF0 ? 0 : P.f_nub[t]) + (int)I.E[t].size();
+            if (t == nFr - 1 && g_opt.inc_tail && I.E[t].empty()) nub += std::max(0, TAIL_POSES - nsb);      // (phantom rows of the last tail front)
+            const int R = 3 * (nsb + nub + 1);
+            all_small = all_small && (small_front_lds(R, R - 3, nw) <= small_max || (g_opt.panel_mode && panel_front_lds(R, 3 * nsb, nw) <= small_max));
+        }
+    }
+    // A plan made of single-workgroup fronts only, one of which has collected so many rows of loop closures since that it no longer
+    // fits the LDS: from here on every step on its root path would take the multi-launch big-front path (and no low-rank
+    // updates).  The structure has outgrown the plan -- a fresh one is cheaper than what follows (measured on the M3500 demo:
+    // 13 such steps, re-planned 505 ms in total, carried on 590 ms).
+    if (!batch && !all_small && !I.base_has_big && g_opt.inc_replan_tall) return inc_fail(17);
     if (!batch && g_opt.inc_update && I.upd_ok && !tail_fast && g_opt.persist && g_opt.inc_multi && g_opt.wave_backsolve) {
         const size_t small_max = (size_t)g_opt.small_lds_kb * 1024;
         const int nw = waves_of(small_threads_for(1));
-        int n_dirty = 0, n_slots = 0;
-        for (int t = 0; t < nFr; t++) n_dirty += I.dirty[t] ? 1 : 0;
-        for (int t = 0; t < nFr && n_dirty <= g_opt.persist_max_fronts; t++) {
+        int n_slots = 0;
+        for (int t = 0; t < nFr && all_small && n_dirty <= g_opt.persist_max_fronts; t++) {
             if (!I.dirty[t] || t == nFr - 1 || t >= grown_lo || mid[t] || I.cur_cap[t] <= 0) continue;      // (t >= grown_lo: its own columns changed)
             const int nsb = t >= nF0 ? I.t_cnt[t - nF0] : P.f_nsb[t], nub = (t >= nF0 ? 0 : P.f_nub[t]) + (int)I.E[t].size();
             const int R = 3 * (nsb + nub + 1);
@@ -1710,7 +1742,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             const int gb = upd ? nbc : tail ? std::max(nbc + 4, TAIL_POSES + (int)E.size() + 4) : nbc + 4;
             const long long want = (long long)(3 * (gb + 1)) * (3 * gb);
             const long long off = (I.pool_used + 31) & ~31ll;
-            if (off + want > I.pool_cap) return false;
+            if (off + want > I.pool_cap) return inc_fail(7);
             D.off = off; I.pool_used = off + want; I.cur_cap[t] = want;
         }
         D.nsb = nsb; D.nub = nub; I.cur_nub[t] = nub;
@@ -1735,7 +1767,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             u.old_off = old_off; u.mode = 1; u.old_nub = old_nub; u.mask = fmask[t];
             u.wout = (int)wbuf_used; wout_of[t] = u.wout;
             wbuf_used += (long long)3 * UPD_MAXF * (3 * nub + 1);
-            if (wbuf_used > (long long)c.d_wbuf.cap) return false;
+            if (wbuf_used > (long long)c.d_wbuf.cap) return inc_fail(8);
             for (int f : I.xfac[t]) {
                 if (f < Fold) continue;
                 const int la = local(fa[f]), lb = fb[f] >= 0 ? local(fb[f]) : -1;
@@ -1818,7 +1850,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     }
     if (I.i32_used + (long long)st_i32.size() > (long long)c.d_i32.cap || I.dest_used + (long long)st_dest.size() > (long long)c.d_dest.cap ||
         I.child_used + (long long)st_child.size() > (long long)c.d_child.cap || (size_t)9 * I.slots_used > c.d_H.cap || (size_t)nFr > c.d_fd.cap ||
-        (size_t)N > c.d_perm.cap) return false;
+        (size_t)N > c.d_perm.cap) return inc_fail(9);
     const double tsub2 = now_ms();
     // ---- 3. launch tables of the dirty fronts (transient region behind the base tables) + back-substitution lists -----
     std::vector<int> &tab = I.st_tab; tab.clear(); std::vector<LevelPlan> dl(nLev);
@@ -1853,7 +1885,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             }
         }
     }
-    if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return false;
+    if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return inc_fail(10);
     for (int l = 0; l < nLev; l++) {
         if (lev_dirty[l].empty()) continue;
         LevelPlan &L = dl[l];
@@ -1873,7 +1905,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             I.base_levels[l].solve_w_lds = std::max(I.base_levels[l].solve_w_lds, backsolve_lds(3 * (P.f_nsb[t] + I.cur_nub[t]), 3 * P.f_nsb[t], true));
         }
     }
-    for (int l = 0; l < nLev; l++) if (diag_doubles(dl[l].n_big, dl[l].n_diag_slots) > c.d_diag.cap) return false;
+    for (int l = 0; l < nLev; l++) if (diag_doubles(dl[l].n_big, dl[l].n_diag_slots) > c.d_diag.cap) return inc_fail(11);
     // batch on the extended plan: levels >= 1 as ONE multi-level launch per sweep (see enqueue_numeric), when they hold small
     // fronts only
     int mp_up_off = 0, mp_dn_off = 0, mp_n = 0, mp_nt = 0; size_t mp_up_lds = 0, mp_dn_lds = 0; long long mp_full = 0; int mp_dn_maxns = 0;
@@ -1902,7 +1934,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap || mp_dn_lds > 160 * 1024) { mp = false; tab.resize(tab_size0); }
     }
     auto solve_lds_of = [&](int t) { return (size_t)(3 * (nsb_of(t) + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8; };
-    for (int t = 0; t < nFr; t++) if (I.need[t] && solve_lds_of(t) > 160 * 1024) return false;
+    for (int t = 0; t < nFr; t++) if (I.need[t] && solve_lds_of(t) > 160 * 1024) return inc_fail(12);
     // incremental step: the regenerated fronts of ALL levels as one multi-level launch (dependency flags, as the batch sweeps
     // do over the top of the tree), and the back substitution from the top as another -- a step that touches a root path is
     // three launches (prologue, fronts, back substitution + state update) instead of one per level and direction
@@ -1926,7 +1958,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     }
     // updated fronts only exist inside that launch (or k_inc_one's loop over the same list): one record per list entry
     if (any_upd) {
-        if (!iu || (size_t)iu_n > c.d_upd.cap || (size_t)3 * nFr > c.d_flags.cap) return false;      // (the eligibility pass checked what iu checks: a full re-plan otherwise)
+        if (!iu || (size_t)iu_n > c.d_upd.cap || (size_t)3 * nFr > c.d_flags.cap) return inc_fail(13);      // (the eligibility pass checked what iu checks: a full re-plan otherwise)
         I.st_upd.resize(iu_n);
         const int sh = (int)I.tab_used;
         for (int i = 0; i < iu_n; i++) {
@@ -1973,8 +2005,8 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         one = one_lds <= 160 * 1024;
     }
     if (!one) { iu = iu && (iu_n >= 2 || any_upd); id = id && id_n >= 2; }
-    if (tail_fast && !one && tail_refactor_lds() > 64 * 1024) return false;       // (never: the refactorisation alone runs as k_inc_one without lists)
-    if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return false;
+    if (tail_fast && !one && tail_refactor_lds() > 64 * 1024) return inc_fail(14);       // (never: the refactorisation alone runs as k_inc_one without lists)
+    if (I.tab_used + (long long)tab.size() > (long long)c.d_tab.cap) return inc_fail(15);
     c.st.reserved0 = (int)fd_dirty.size();              // fronts regenerated by this step (tools/inc_hist.py)
     if (!batch) {
         int nu_ = 0; for (int t : fd_dirty) nu_ += (any_upd && mode[t]) ? 1 : 0;
@@ -1988,7 +2020,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     PatchList &PL = c.patches;
     PL.reset();
     {   // new factors (what upload_factors would copy)
-        if (F > gp.F_cap) return false;                        // device arrays must grow: the re-plan path re-uploads
+        if (F > gp.F_cap) return inc_fail(16);                        // device arrays must grow: the re-plan path re-uploads
         const int f0 = gp.F_on_device;
         if (F > f0) {
             PL.add(gp.d_fa.p + f0, gp.h_fa.p + f0, (size_t)(F - f0) * 4); PL.add(gp.d_fb.p + f0, gp.h_fb.p + f0, (size_t)(F - f0) * 4);
@@ -2226,12 +2258,13 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         if (grew) { c.want_inc = true; c.same_topo_batches = 0; }        // (plans made from now on reserve the append slack)
         else if (ext && !c.inc.t_first.empty()) c.same_topo_batches++;
         const int tails_after = (N - c.inc.Nb + 23) / 24;               // (extend_tail_fronts counts tail fronts of 24 poses, whatever tail_poses is)
+        const double lam = param->tikhanov > 0 ? param->tikhanov : 0.0;
         if (ext && N > c.inc.Nb && c.inc.cap_nodes > 0 && tails_after <= g_opt.extend_tail_fronts && (grew || (!c.inc.t_first.empty() && c.same_topo_batches <= 1))) {
             // z / W of already-packed factors edited in place by the caller (pack_factors recorded the range) only reach the
             // device through upload_factors: the patch list of inc_fast_step carries the NEW factors alone
             if (F > gp.F_cap || gp.dirty_hi > gp.dirty_lo) upload_factors(gp);
             c.h_bad.need(4);
-            hybrid = inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, nullptr, param->tikhanov > 0 ? param->tikhanov : 0.0);
+            hybrid = inc_fast_step(c, gp, N, F, c.inc_F, c.inc_N, nullptr, lam);
             reused = hybrid;
         }
     }
@@ -2372,6 +2405,8 @@ struct IncProf {
                                 g_incsub_n, 1e3 * g_incsub[0] / g_incsub_n, 1e3 * g_incsub[1] / g_incsub_n, 1e3 * g_incsub[2] / g_incsub_n, 1e3 * g_incsub[3] / g_incsub_n, 1e3 * g_incsub[4] / g_incsub_n, g_incsub[5] / g_incsub_n, g_incsub[6], g_incsub[7]);
         fprintf(stderr, "aprilsam_amd inc profile, low-rank updates: %lld general-path steps with updated fronts (%lld fronts updated, %lld re-factorised), %lld without (%lld fronts re-factorised); %lld of all of them as one launch\n",
                 g_updstat[0], g_updstat[2], g_updstat[3], g_updstat[1], g_updstat[4], g_updstat[5]);
+        { std::string r; for (int k = 0; k < 32; k++) if (g_incfail[k]) r += " #" + std::to_string(k) + ":" + std::to_string(g_incfail[k]);
+          fprintf(stderr, "aprilsam_amd inc profile, steps handed to a full re-plan by exit of inc_fast_step:%s\n", r.empty() ? " none" : r.c_str()); }
         if (!kst.empty()) {
             double km[4];
             for (int k = 0; k < 4; k++) {
@@ -3555,6 +3590,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "inc_update") g_opt.inc_update = (int)v;
     else if (k == "inc_tail_solve") g_opt.inc_tail_solve = (int)v;
     else if (k == "inc_lazy_states") g_opt.inc_lazy_states = (int)v;
+    else if (k == "inc_replan_tall") g_opt.inc_replan_tall = (int)v;
     else if (k == "speculate_factors") g_opt.speculate_factors = (int)v;
     else if (k == "block_factor") g_opt.block_factor = (int)v;
     else if (k == "pin_last") g_opt.pin_last = (int)v;
@@ -3573,7 +3609,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "mem_cap_mb") g_opt.mem_cap_mb = (int)v;
     else return -1;
     // host-side policies that no launch table or captured graph depends on
-    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "inc_multi", "inc_one", "inc_one_up", "inc_one_dn", "inc_one_threads", "inc_one_spin", "inc_inline", "inc_update", "inc_tail_solve", "inc_lazy_states", "speculate_factors", "batch_extend",
+    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "inc_multi", "inc_one", "inc_one_up", "inc_one_dn", "inc_one_threads", "inc_one_spin", "inc_inline", "inc_update", "inc_tail_solve", "inc_lazy_states", "inc_replan_tall", "speculate_factors", "batch_extend",
                                              "extend_tail_fronts", "mem_cap_mb", "medium_lds_kb" };
     bool policy = false;
     for (const char *q : no_replan) policy = policy || k == q;

@@ -275,7 +275,7 @@ void aprilsam_amd_clear_error(void);
  *   "syrk128_rows"      trailing updates at least this tall use the LDS-staged 128x128 MFMA kernel (default off)
  *   "batch_extend"      1 (default): april_graph_cholesky on a graph that only GREW since the last plan keeps the plan -- the
  *                       appended poses become tail fronts, every front is re-factorised (batch semantics) -- instead of a new
- *                       ordering + symbolic analysis per call; once more than "extend_tail_fronts" (default 8) x 24 poses have been
+ *                       ordering + symbolic analysis per call; once more than "extend_tail_fronts" (default 3) x 24 poses have been
  *                       appended (the unit is fixed at 24 poses whatever "tail_poses" -- default 28 -- says), or when the topology stops
  *                       changing, a full re-plan follows.  0 = re-plan on every topology change
  *   "pin_last"          k > 0: the k newest poses are kept out of the nested dissection and form the root front ("recent
