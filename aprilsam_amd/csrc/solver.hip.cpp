@@ -193,8 +193,11 @@ struct PatchList {
 static long long g_pack_serial = 0;
 struct GraphPack {
     const long long serial = ++g_pack_serial;      // captured hipGraphs are keyed by it: a pack freed and another allocated at the same addresses must not match
-    int N = 0, F = 0;                  // packed counts
-    std::vector<const void *> fptr;    // factor object pointers already packed (cache validation)
+    int N = 0, F = 0;                  // packed counts (F: packed factor entries, see pack_factors)
+    int Fg = 0;                        // graph factors packed (== F unless a factor has more than two nodes)
+    std::vector<int> g2p, p2g;         // graph factor -> its first packed entry (size Fg + 1) / packed entry -> graph factor
+    std::vector<unsigned> vslot;       // per packed entry of a host-evaluated factor: node slots (x << 8 | y; y = 0xff: unary) | carry bits << 16
+    std::vector<const void *> fptr;    // factor object pointers already packed (cache validation), one per graph factor
     std::vector<int> pending;          // poses whose pinned state mirror is ahead of the device copy (written by apply_visits)
     HBuf<int> h_fa, h_fb;
     HBuf<double> h_z, h_W, h_state, h_lp, h_dx;
@@ -250,74 +253,101 @@ static inline int zsize(const zarray_t *z) { return z ? z->size : 0; }
 // (nodes, z, W: 104 bytes) and only what changed is copied and uploaded again; a changed endpoint or factor kind
 // restarts the pack.  Option trust_factor_cache = 1 skips the comparison for factors whose object pointer is unchanged
 // (z / W of a packed factor are then treated as immutable).
+//
+// PACKED factors are what everything below this function sees: one entry per graph factor with one or two nodes, and for a
+// factor with k >= 3 nodes (foreign types only, evaluated through their own eval(): the reference's assembly loops are
+// generic over factor->nnodes, aprilsam.c:159-192) one entry per PAIR of its nodes, k (k - 1) / 2 of them -- the pair (i, j)
+// carries the off-diagonal block J_i^T W J_j; the diagonal block and the right-hand-side segment of node i ride on the
+// first pair that contains i.  A clique of binary entries is exactly the structure such a factor has in the normal
+// equations, so ordering, symbolic analysis and kernels need not know.  gp.F counts packed entries, gp.Fg graph factors
+// (param->factor_num, aprilsam.c:283-288); g2p / p2g translate.
 static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_old = true) {
     const bool trust = g_opt.trust_factor_cache || !validate_old;      // (incremental calls never re-read old factors, aprilsam.c:508-511)
-    const int F = zsize(g->factors);
+    const int Fg = zsize(g->factors);
     april_graph_factor_t **fs = (april_graph_factor_t **)g->factors->data;
     const int N = zsize(g->nodes);
-    int from = gp.F;
-    bool valid = from <= F && (int)gp.fptr.size() == from;
+    int from = gp.Fg;
+    bool valid = from <= Fg && (int)gp.fptr.size() == from && (int)gp.g2p.size() == from + 1;
     // (incremental calls only ever look at the factors added since the previous call, aprilsam.c:508-511: first and last packed pointer
     // as a sanity check instead of all of them -- the comparison of 5 000 pointers was a microsecond of every step)
     if (valid && trust) valid = from == 0 || (validate_old ? memcmp(gp.fptr.data(), fs, sizeof(void *) * from) == 0 : (gp.fptr[0] == fs[0] && gp.fptr[from - 1] == fs[from - 1]));
-    if (!valid) { from = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; gp.is_host.clear(); }
-    gp.h_fa.need(F, true); gp.h_fb.need(F, true); gp.h_z.need((size_t)3 * F, true); gp.h_W.need((size_t)9 * F, true);
-    gp.fptr.resize(F); gp.is_host.resize(F, 0);
-    auto classify = [&](const april_graph_factor_t *f, int i, int *a, int *b) -> bool {      // returns host_eval
-        bool host_eval = false;
-        *a = -1; *b = -1;
-        if (f->type == APRIL_GRAPH_FACTOR_XYT_TYPE && f->nnodes == 2) { *a = f->nodes[0]; *b = f->nodes[1]; }
-        else if (f->type == APRIL_GRAPH_FACTOR_XYTPOS_TYPE && f->nnodes == 1) { *a = f->nodes[0]; *b = -1; }
-        else if ((f->nnodes == 1 || f->nnodes == 2) && f->eval) {     // any other type: the factor's own eval(), on the host
-            *a = f->nodes[0]; *b = f->nnodes == 2 ? f->nodes[1] : -1; host_eval = true;
+    auto restart = [&]() { from = 0; gp.F = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; gp.is_host.clear(); gp.p2g.clear(); gp.vslot.clear(); gp.g2p.assign(1, 0); };
+    if (!valid) restart();
+    // one graph factor -> its packed entries (a, b, host flag, node slots of a host pair, what the pair carries)
+    struct Ent { int a, b; bool host; unsigned short slots; unsigned char carry; };
+    Ent ents[64]; int ne = 0;
+    auto classify = [&](const april_graph_factor_t *f, int i) {
+        ne = 0;
+        if (f->type == APRIL_GRAPH_FACTOR_XYT_TYPE && f->nnodes == 2) ents[ne++] = Ent{ f->nodes[0], f->nodes[1], false, 0, 3 };
+        else if (f->type == APRIL_GRAPH_FACTOR_XYTPOS_TYPE && f->nnodes == 1) ents[ne++] = Ent{ f->nodes[0], -1, false, 0, 3 };
+        else if ((f->nnodes == 1 || f->nnodes == 2) && f->eval)       // any other type: the factor's own eval(), on the host
+            ents[ne++] = Ent{ f->nodes[0], f->nnodes == 2 ? f->nodes[1] : -1, true, (unsigned short)(f->nnodes == 2 ? 1 : 0xff), 3 };
+        else if (f->nnodes >= 3 && f->nnodes <= 11 && f->eval) {      // a clique of pairs (see above); 11 nodes = 55 pairs
+            for (int x = 0; x < f->nnodes; x++)
+                for (int y = x + 1; y < f->nnodes; y++) {
+                    // node x's diagonal block / rhs on its first pair: (0, 1) for x = 0 and x = 1, (0, x) beyond
+                    const unsigned char carry = (unsigned char)(((x == 0 && y == 1) ? 1 : 0) | ((x == 0) ? 2 : 0));
+                    ents[ne++] = Ent{ f->nodes[x], f->nodes[y], true, (unsigned short)((x << 8) | y), carry };
+                }
         } else {
-            fail(ERR_UNSUPPORTED, "factor %d has type %d / %d nodes; factors of foreign types are supported with one or two nodes and an "
+            fail(ERR_UNSUPPORTED, "factor %d has type %d / %d nodes; factors of foreign types are supported with 1 to 11 nodes and an "
                                   "eval() function pointer (aprilsam.h:110-122)", i, f->type, f->nnodes);
         }
-        if (*a < 0 || *a >= N || *b >= N) fail(ERR_BAD_GRAPH, "factor %d references node %d / %d of %d", i, *a, *b, N);
-        if (*a == *b) fail(ERR_BAD_GRAPH, "factor %d connects node %d to itself", i, *a);
-        return host_eval;
+        for (int e = 0; e < ne; e++) {
+            if (ents[e].a < 0 || ents[e].a >= N || ents[e].b >= N) fail(ERR_BAD_GRAPH, "factor %d references node %d / %d of %d", i, ents[e].a, ents[e].b, N);
+            if (ents[e].a == ents[e].b) fail(ERR_BAD_GRAPH, "factor %d connects node %d to itself", i, ents[e].a);
+        }
     };
     if (from > 0 && !trust) {
         // content check of the packed prefix; dirty range [lo, hi) is uploaded again by upload_factors
-        int lo = from, hi = 0;
-        bool restart = false;
+        int lo = gp.F, hi = 0;
+        bool changed = false;
         for (int i = 0; i < from; i++) {
             if (i + 8 < from) __builtin_prefetch(fs[i + 8]);
             const april_graph_factor_t *f = fs[i];
-            int a, b;
-            const bool host_eval = classify(f, i, &a, &b);
-            if (a != gp.h_fa.p[i] || b != gp.h_fb.p[i] || host_eval != (bool)gp.is_host[i]) { restart = true; break; }
+            classify(f, i);
+            const int p0 = gp.g2p[i];
+            if (gp.g2p[i + 1] - p0 != ne) { changed = true; break; }
+            for (int e = 0; e < ne && !changed; e++)
+                changed = ents[e].a != gp.h_fa.p[p0 + e] || ents[e].b != gp.h_fb.p[p0 + e] || ents[e].host != (bool)gp.is_host[p0 + e];
+            if (changed) break;
             gp.fptr[i] = f;
-            if (host_eval) continue;
-            double *zp = gp.h_z.p + (size_t)3 * i, *Wp = gp.h_W.p + (size_t)9 * i;
+            if (ents[0].host) continue;
+            double *zp = gp.h_z.p + (size_t)3 * p0, *Wp = gp.h_W.p + (size_t)9 * p0;
             if (memcmp(zp, f->u.common.z, 24) != 0 || memcmp(Wp, f->u.common.W->data, 72) != 0) {
                 memcpy(zp, f->u.common.z, 24); memcpy(Wp, f->u.common.W->data, 72);
-                lo = std::min(lo, i); hi = std::max(hi, i + 1);
+                lo = std::min(lo, p0); hi = std::max(hi, p0 + 1);
             }
         }
-        if (restart) { from = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; }
+        if (changed) restart();
         else if (hi > lo) {
             if (gp.dirty_hi > gp.dirty_lo) { gp.dirty_lo = std::min(gp.dirty_lo, lo); gp.dirty_hi = std::max(gp.dirty_hi, hi); }
             else { gp.dirty_lo = lo; gp.dirty_hi = hi; }
             gp.content_version++;
         }
     }
-    for (int i = from; i < F; i++) {
+    gp.fptr.resize(Fg); gp.g2p.resize((size_t)Fg + 1);
+    int F = gp.g2p[from];
+    for (int i = from; i < Fg; i++) {
         const april_graph_factor_t *f = fs[i];
         gp.fptr[i] = f;
-        int a, b;
-        const bool host_eval = classify(f, i, &a, &b);
-        gp.h_fa.p[i] = a; gp.h_fb.p[i] = b; gp.is_host[i] = host_eval;
-        if (host_eval) {          // the device kernels see a null factor (W = 0) in its place; k_scatter_host fills its slots
-            memset(gp.h_z.p + (size_t)3 * i, 0, 24); memset(gp.h_W.p + (size_t)9 * i, 0, 72);
-            gp.host_idx.push_back(i);
-        } else {
-            memcpy(gp.h_z.p + (size_t)3 * i, f->u.common.z, 24);
-            memcpy(gp.h_W.p + (size_t)9 * i, f->u.common.W->data, 72);
+        classify(f, i);
+        gp.h_fa.need((size_t)F + ne, true); gp.h_fb.need((size_t)F + ne, true); gp.h_z.need((size_t)3 * (F + ne), true); gp.h_W.need((size_t)9 * (F + ne), true);
+        gp.is_host.resize((size_t)F + ne, 0); gp.p2g.resize((size_t)F + ne); gp.vslot.resize((size_t)F + ne);
+        for (int e = 0; e < ne; e++, F++) {
+            gp.h_fa.p[F] = ents[e].a; gp.h_fb.p[F] = ents[e].b; gp.is_host[F] = ents[e].host; gp.p2g[F] = i;
+            gp.vslot[F] = (unsigned)ents[e].slots | ((unsigned)ents[e].carry << 16);
+            if (ents[e].host) {          // the device kernels see a null factor (W = 0) in its place; k_scatter_host fills its slots
+                memset(gp.h_z.p + (size_t)3 * F, 0, 24); memset(gp.h_W.p + (size_t)9 * F, 0, 72);
+                gp.host_idx.push_back(F);
+            } else {
+                memcpy(gp.h_z.p + (size_t)3 * F, f->u.common.z, 24);
+                memcpy(gp.h_W.p + (size_t)9 * F, f->u.common.W->data, 72);
+            }
         }
+        gp.g2p[i + 1] = F;
     }
-    gp.F = F;
+    gp.F = F; gp.Fg = Fg;
 }
 static void upload_factors(GraphPack &gp) {
     const int F = gp.F;
@@ -351,33 +381,49 @@ static double eval_host_factors(GraphPack &gp, april_graph_t *g, int from) {
     gp.h_hostH.need((size_t)33 * std::max(nh, 1), true);
     april_graph_factor_t **fs = (april_graph_factor_t **)g->factors->data;
     double chi2 = 0;
+    april_graph_factor_eval_t *e = nullptr; int e_of = -1;         // (the pairs of a factor with more than two nodes share one evaluation)
+    std::vector<double> JtW;
     for (int k = from; k < nh; k++) {
-        april_graph_factor_t *f = fs[gp.host_idx[k]];
-        april_graph_factor_eval_t *e = f->eval(f, g, nullptr);
-        if (!e || !e->jacobians || !e->jacobians[0] || !e->W || !e->r) fail(ERR_BAD_GRAPH, "factor->eval returned an incomplete evaluation (aprilsam.h:75-89)");
+        const int hp = gp.host_idx[k], gi = gp.p2g[hp];
+        april_graph_factor_t *f = fs[gi];
+        const int x = (int)((gp.vslot[hp] >> 8) & 0xff), y = (int)(gp.vslot[hp] & 0xff), carry = (int)(gp.vslot[hp] >> 16);
+        if (gi != e_of) {
+            if (e) april_graph_factor_eval_destroy(e);
+            e = f->eval(f, g, nullptr); e_of = gi;
+            if (!e || !e->jacobians || !e->jacobians[0] || !e->W || !e->r) fail(ERR_BAD_GRAPH, "factor->eval returned an incomplete evaluation (aprilsam.h:75-89)");
+            chi2 += e->chi2;
+        }
         const int L = e->length;
         double *H = gp.h_hostH.p + (size_t)33 * k;
         memset(H, 0, 33 * 8);
-        std::vector<double> JtW((size_t)3 * L);
-        for (int z0 = 0; z0 < f->nnodes; z0++) {
+        JtW.resize((size_t)3 * L);
+        const int zs[2] = { x, y == 0xff ? -1 : y };
+        for (int s0 = 0; s0 < 2; s0++) {
+            const int z0 = zs[s0];
+            if (z0 < 0) continue;
             const matd_t *J0 = e->jacobians[z0];
-            if (!J0 || (int)J0->nrows != L || J0->ncols != 3 || (int)e->W->nrows != L || (int)e->W->ncols != L)
+            if (!J0) fail(ERR_BAD_GRAPH, "factor->eval: fewer jacobians than nodes");
+            if ((int)J0->nrows != L || J0->ncols != 3 || (int)e->W->nrows != L || (int)e->W->ncols != L)
                 fail(ERR_UNSUPPORTED, "factor->eval: jacobians must be length x 3 and W length x length (3-DoF xyt nodes only, aprilsam.c:617)");
             for (int i = 0; i < 3; i++)
                 for (int l = 0; l < L; l++) { double acc = 0; for (int m = 0; m < L; m++) acc += J0->data[m * 3 + i] * e->W->data[m * L + l]; JtW[(size_t)i * L + l] = acc; }
-            for (int z1 = z0; z1 < f->nnodes; z1++) {
+            for (int s1 = s0; s1 < 2; s1++) {
+                const int z1 = zs[s1];
+                if (z1 < 0) continue;
+                if (s1 == s0 && !((carry >> s0) & 1)) continue;      // this node's diagonal block rides on another pair of the factor
                 const matd_t *J1 = e->jacobians[z1];
                 if (!J1) fail(ERR_BAD_GRAPH, "factor->eval: fewer jacobians than nodes");
-                double *B = H + (z0 == 0 ? (z1 == 0 ? 0 : 9) : 18);
+                double *B = H + (s0 == 0 ? (s1 == 0 ? 0 : 9) : 18);
                 for (int i = 0; i < 3; i++)
                     for (int j = 0; j < 3; j++) { double acc = 0; for (int l = 0; l < L; l++) acc += JtW[(size_t)i * L + l] * J1->data[l * 3 + j]; B[i * 3 + j] = acc; }
             }
-            double *gv = H + 27 + 3 * z0;
-            for (int i = 0; i < 3; i++) { double acc = 0; for (int l = 0; l < L; l++) acc += JtW[(size_t)i * L + l] * e->r[l]; gv[i] = acc; }
+            if ((carry >> s0) & 1) {
+                double *gv = H + 27 + 3 * s0;
+                for (int i = 0; i < 3; i++) { double acc = 0; for (int l = 0; l < L; l++) acc += JtW[(size_t)i * L + l] * e->r[l]; gv[i] = acc; }
+            }
         }
-        chi2 += e->chi2;
-        april_graph_factor_eval_destroy(e);
     }
+    if (e) april_graph_factor_eval_destroy(e);
     gp.host_evaluated = nh;
     return chi2;
 }
@@ -2224,8 +2270,8 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     // from the fresh copies: nothing of the first run is visible (its inputs are the pinned state mirror, which it does not
     // write; its outputs are overwritten).
     const bool timing0 = g_opt.device_timing != 0;
-    bool speculate = g_opt.speculate_factors && !g_opt.trust_factor_cache && !timing0 && c.have_plan && gp.F > 0 && gp.F == zsize(g->factors) && gp.N == zsize(g->nodes) &&
-                     (int)gp.fptr.size() == gp.F && gp.host_idx.empty() && gp.F_on_device == gp.F && gp.dirty_hi <= gp.dirty_lo &&
+    bool speculate = g_opt.speculate_factors && !g_opt.trust_factor_cache && !timing0 && c.have_plan && gp.F > 0 && gp.Fg == zsize(g->factors) && gp.N == zsize(g->nodes) &&
+                     (int)gp.fptr.size() == gp.Fg && gp.host_idx.empty() && gp.F_on_device == gp.F && gp.dirty_hi <= gp.dirty_lo &&
                      c.patN == gp.N && (int)c.pat.size() == 2 * gp.F && c.inc.t_first.empty() && c.plan_persist == launch_table_key() &&
                      c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last && g_opt.use_graph && !param->show_timing && !c.no_speculation;
     c.no_speculation = false; c.st.reserved1 = 0; c.st.inc_replanned = 0; c.st.inc_old_old_cross = 0;
@@ -2331,7 +2377,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
         memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
         param->nreordering = N;
-        param->factor_num = F;
+        param->factor_num = gp.Fg;      // (graph factors; F counts packed entries, pack_factors)
         c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = model_ready;
         if (!hybrid) inc_prepare(c);                     // (an extended plan keeps its base + tail bookkeeping)
         c.inc_F = F; c.inc_N = N;
@@ -2543,7 +2589,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
     memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
     param->nreordering = N;
-    param->factor_num = F;
+    param->factor_num = gp.Fg;
     const double step_ms = now_ms() - t0;
     c.st.ms_total = step_ms;
     if (param->show_timing)
@@ -2705,8 +2751,12 @@ static double chi2_impl(april_graph_t *g) {
     double chi2 = device_chi2(gp);
     if (!gp.host_idx.empty()) {       // april_graph.c:90-93: factors other than xyt contribute eval()->chi2
         april_graph_factor_t **fs = (april_graph_factor_t **)g->factors->data;
+        int last = -1;
         for (int idx : gp.host_idx) {
-            april_graph_factor_eval_t *e = fs[idx]->eval(fs[idx], g, nullptr);
+            const int gi = gp.p2g[idx];
+            if (gi == last) continue;                      // (the pairs of a factor with more than two nodes: one evaluation)
+            last = gi;
+            april_graph_factor_eval_t *e = fs[gi]->eval(fs[gi], g, nullptr);
             chi2 += e->chi2;
             april_graph_factor_eval_destroy(e);
         }
@@ -2819,7 +2869,7 @@ static int resident_end_impl(april_graph_t *g, april_graph_cholesky_param_t *par
     if (param->ordering) free(param->ordering);
     param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
     memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
-    param->nreordering = N; param->factor_num = F;
+    param->nreordering = N; param->factor_num = gp.Fg;
     c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = false;
     inc_prepare(c); c.inc_F = F; c.inc_N = N;
     record_unary_points(gp, 0, F, gp.h_lp.p);                // (unary factors were last linearised at the final l_points)
@@ -3442,7 +3492,7 @@ static int shard_gather_states_impl(april_graph_t *g, april_graph_cholesky_param
     if (param->ordering) free(param->ordering);
     param->ordering = (int *)malloc(sizeof(int) * (size_t)N);
     memcpy(param->ordering, c.plan.perm.data(), sizeof(int) * (size_t)N);
-    param->nreordering = N; param->factor_num = gp.F;
+    param->nreordering = N; param->factor_num = gp.Fg;
     return 0;
 }
 // chi^2 at the resident states: every rank sums the factors its fronts own, the transport adds the partial sums

@@ -239,7 +239,8 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *     -2  a pivot was not positive (stats.not_spd = 1; information matrix not positive definite)
  *     -9  a multi-level launch gave up waiting for a dependency flag (should not happen; reported, not hung)
  *    -10  a HIP runtime call failed                  -11  device / pinned memory exhausted (or option "mem_cap_mb")
- *    -12  unsupported input: node type other than xyt, factor with more than two nodes, an unsplittable dense region of
+ *    -12  unsupported input: node type other than xyt, a foreign factor (own eval()) with more than 11 nodes, a factor of a native type
+ *         with the wrong number of nodes, an unsplittable dense region of
  *         more than ~6000 poses, more than 22 million factors, param->nreordering == 0 (the reference asserts)
  *    -13  malformed graph: node index out of range, a factor connecting a node to itself, incomplete eval() result
  *    -14  no HIP device visible: there is NO CPU fallback, every solver call on such a machine fails this way (april_graph_chi2

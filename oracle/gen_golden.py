@@ -58,6 +58,9 @@ def main():
         out = custom_scenario.run(ref, cl)
         np.savez_compressed(os.path.join(GOLD, "custom_factors.npz"), **out)
         print("custom factors: chi2", out["chi2"])
+        out3 = custom_scenario.run(ref, cl, triples=8)          # ... with three-pose factors (factor->nnodes == 3)
+        np.savez_compressed(os.path.join(GOLD, "custom_factors3.npz"), **out3)
+        print("custom factors incl. three-pose ones: chi2", out3["chi2"])
         return
     prod = host.SolverLib()          # only its data generators are used here (lattice arrays)
 

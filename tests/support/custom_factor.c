@@ -6,7 +6,10 @@
  *
  *   type 77  "xy"       two poses, 2 residuals: position of b in a's frame, r = z - h(a, b), W 2x2
  *   type 78  "heading"  one pose, 1 residual: r = wrap(z - theta), W 1x1
- * Both linearise at the nodes' l_point in eval() and at state in state_eval().
+ *   type 79  "midpoint" THREE poses a, b, c, 2 residuals: b seen from the midpoint of a and c, in a's heading,
+ *                       r = z - R(theta_a)^T (p_b - (p_a + p_c) / 2), W 2x2 -- exercises factor->nnodes > 2, which the
+ *                       reference's assembly loops handle generically (aprilsam.c:159-192)
+ * All linearise at the nodes' l_point in eval() and at state in state_eval().
  *
  *   gcc -O2 -fPIC -shared -Iinclude tests/support/custom_factor.c -o <out>.so -lm
  */
@@ -97,5 +100,47 @@ april_graph_factor_t *custom_heading_create(int a, double z, double w) {
     f->copy = hd_copy; f->eval = hd_eval; f->state_eval = hd_state_eval; f->destroy = common_destroy;
     f->u.common.z = (double *)calloc(1, sizeof(double)); f->u.common.z[0] = z;
     f->u.common.W = matd_new(1, 1); f->u.common.W->data[0] = w;
+    return f;
+}
+
+/* ---------------------------------------------------------------- type 79 */
+static april_graph_factor_eval_t *mid_eval_at(april_graph_factor_t *f, april_graph_t *g, april_graph_factor_eval_t *e, int at_state) {
+    if (!e) {
+        e = (april_graph_factor_eval_t *)calloc(1, sizeof(*e));
+        e->jacobians = (matd_t **)calloc(4, sizeof(matd_t *));
+        for (int k = 0; k < 3; k++) e->jacobians[k] = matd_new(2, 3);
+        e->r = (double *)calloc(2, sizeof(double));
+        e->W = matd_new(2, 2);
+    }
+    e->length = 2;
+    const double *p[3];
+    for (int k = 0; k < 3; k++) p[k] = at_state ? node_of(g, f->nodes[k])->state : node_of(g, f->nodes[k])->l_point;
+    const double c = cos(p[0][2]), s = sin(p[0][2]);
+    const double d0 = p[1][0] - 0.5 * (p[0][0] + p[2][0]), d1 = p[1][1] - 0.5 * (p[0][1] + p[2][1]);
+    const double h0 = c * d0 + s * d1, h1 = -s * d0 + c * d1;
+    double *Ja = e->jacobians[0]->data, *Jb = e->jacobians[1]->data, *Jc = e->jacobians[2]->data;
+    Ja[0] = -0.5 * c; Ja[1] = -0.5 * s; Ja[2] = h1;
+    Ja[3] = 0.5 * s;  Ja[4] = -0.5 * c; Ja[5] = -h0;
+    Jb[0] = c;  Jb[1] = s; Jb[2] = 0;
+    Jb[3] = -s; Jb[4] = c; Jb[5] = 0;
+    Jc[0] = -0.5 * c; Jc[1] = -0.5 * s; Jc[2] = 0;
+    Jc[3] = 0.5 * s;  Jc[4] = -0.5 * c; Jc[5] = 0;
+    e->r[0] = f->u.common.z[0] - h0; e->r[1] = f->u.common.z[1] - h1;
+    memcpy(e->W->data, f->u.common.W->data, 4 * sizeof(double));
+    const double *W = e->W->data;
+    e->chi2 = e->r[0] * (W[0] * e->r[0] + W[1] * e->r[1]) + e->r[1] * (W[2] * e->r[0] + W[3] * e->r[1]);
+    return e;
+}
+static april_graph_factor_eval_t *mid_eval(april_graph_factor_t *f, april_graph_t *g, april_graph_factor_eval_t *e) { return mid_eval_at(f, g, e, 0); }
+static april_graph_factor_eval_t *mid_state_eval(april_graph_factor_t *f, april_graph_t *g, april_graph_factor_eval_t *e) { return mid_eval_at(f, g, e, 1); }
+april_graph_factor_t *custom_midpoint_create(int a, int b, int c, const double *z, const double *W4);
+static april_graph_factor_t *mid_copy(april_graph_factor_t *f) { return custom_midpoint_create(f->nodes[0], f->nodes[1], f->nodes[2], f->u.common.z, f->u.common.W->data); }
+april_graph_factor_t *custom_midpoint_create(int a, int b, int c, const double *z, const double *W4) {
+    april_graph_factor_t *f = (april_graph_factor_t *)calloc(1, sizeof(*f));
+    f->type = 79; f->nnodes = 3; f->length = 2;
+    f->nodes = (int *)calloc(3, sizeof(int)); f->nodes[0] = a; f->nodes[1] = b; f->nodes[2] = c;
+    f->copy = mid_copy; f->eval = mid_eval; f->state_eval = mid_state_eval; f->destroy = common_destroy;
+    f->u.common.z = (double *)calloc(2, sizeof(double)); memcpy(f->u.common.z, z, 2 * sizeof(double));
+    f->u.common.W = matd_new(2, 2); memcpy(f->u.common.W->data, W4, 4 * sizeof(double));
     return f;
 }

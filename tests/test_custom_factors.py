@@ -25,6 +25,11 @@ def test_reference_reproduces_the_custom_factor_golden(reflib, custom):
     _check(custom_scenario.run(reflib, custom), golden("custom_factors.npz"), 1e-12)
 
 
+def test_reference_reproduces_the_three_pose_factor_golden(reflib, custom):
+    """... and the fixture with factors of THREE poses (factor->nnodes == 3, aprilsam.c:159-192 is generic over it)"""
+    _check(custom_scenario.run(reflib, custom, triples=8), golden("custom_factors3.npz"), 1e-12)
+
+
 def test_custom_factor_helper_is_consistent(custom):
     """the helper's objects have the public layout and a working destroy entry"""
     import ctypes as C
@@ -40,6 +45,17 @@ def test_custom_factor_helper_is_consistent(custom):
 def test_custom_factors_match_reference_golden(lib, custom):
     out = custom_scenario.run(lib, custom)
     _check(out, golden("custom_factors.npz"), 1e-6)
+
+
+@pytest.mark.gpu
+def test_factors_with_three_poses_match_reference_golden(lib, custom):
+    """round 4: a foreign factor with more than two nodes is packed as the clique of its node pairs (each pair carries one
+    off-diagonal block J_i^T W J_j; a node's diagonal block and right-hand-side segment ride on its first pair) -- 8 such factors
+    in the batch graph, one more in each of the two incremental steps, against the unmodified reference; param->factor_num
+    keeps counting GRAPH factors"""
+    G = golden("custom_factors3.npz")
+    out = custom_scenario.run(lib, custom, triples=8)
+    _check(out, G, 1e-6)
 
 
 @pytest.mark.gpu

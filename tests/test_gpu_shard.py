@@ -25,11 +25,16 @@ def _worker(rank, world, port, K, iters, out, backend="gloo", env=None):
     from aprilsam_amd.shard import ShardedSolver
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = host.SolverLib()
+    if (env or {}).get("ONE_DEVICE_PER_RANK"):
+        assert lib.dll.aprilsam_amd_set_device(rank) == 0        # (before the first solver call: this rank's contexts live on device `rank`)
     g = lib.new_graph(); lib.dll.aprilsam_amd_make_lattice(g.ptr, K); p = lib.new_param()
     pretend = (env or {}).get("PRETEND_RCCL_UNAVAILABLE_ON")
     sol = ShardedSolver(lib, g, p, rank, world, backend=backend, _pretend_rccl_unavailable_on=pretend)
-    if env:
+    if pretend is not None:
         assert sol.transport_note and "host callbacks over gloo" in sol.comm_info()["transport"], sol.comm_info()
+    if (env or {}).get("ONE_DEVICE_PER_RANK"):
+        ci = sol.comm_info()                                     # the wire really is RCCL, one rank per device
+        assert ci["transport"].startswith("RCCL") and ci["ncclCommCount"] == world and ci["ncclCommUserRank"] == rank and ci["hip_device"] == rank, ci
     chi2 = [sol.chi2()]
     for _ in range(iters):
         sol.iterate(1)
@@ -134,6 +139,27 @@ def test_rccl_unavailable_on_one_rank_falls_back_to_host_callbacks_everywhere(bu
     res, st = _run(2, K, iters, backend="nccl", env={"PRETEND_RCCL_UNAVAILABLE_ON": "1"})
     c1, s1 = _single_gpu_states(lib, K, iters)
     _check(res, st, 2, G["chi2"], s1)
+
+
+@pytest.mark.parametrize("K", [316, 1000])
+def test_rccl_wire_between_devices(built, lib, K):
+    """Config 5 as BASELINE.json states it -- one rank per MI355X, Schur slabs and separator solutions over RCCL / xGMI --
+    on as many devices as the box has (2, 4 or 8): auto-skips on a single-GPU box (the builder's and the round-end test
+    machine), so that the first multi-GPU box that runs this suite exercises the wire: RCCL reports one rank per device,
+    chi^2 equals the single-GPU trace to 1e-9 and the gathered states a single-GPU run to 1e-9, bit-identical on every rank."""
+    ndev = lib.device_count()
+    if ndev < 2:
+        pytest.skip(f"{ndev} HIP device(s) visible: the RCCL wire needs at least two")
+    world = 8 if ndev >= 8 else 4 if ndev >= 4 else 2
+    if K == 316:
+        G = np.load(os.path.join(ROOT, "tests", "golden", "lattice_316.npz"))
+        want = G["chi2"]; iters = len(want) - 1
+    else:
+        import bench
+        want = np.array(bench.LATTICE1M_CHI2[:2]); iters = 1
+    res, st = _run(world, K, iters, timeout=1500, backend="nccl", env={"ONE_DEVICE_PER_RANK": "1"})
+    c1, s1 = _single_gpu_states(lib, K, iters)
+    _check(res, st, world, want, s1)
 
 
 def test_rccl_transport_on_one_rank(built, lib):
