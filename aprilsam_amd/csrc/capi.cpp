@@ -69,6 +69,7 @@ int aprilsam_amd_resident_steps(april_graph_t *graph, april_graph_cholesky_param
 int aprilsam_amd_resident_sync(april_graph_t *graph, april_graph_cholesky_param_t *param) { return asam::resident_sync(graph, param); }
 double aprilsam_amd_resident_chi2(april_graph_t *graph) { return asam::resident_chi2(graph); }
 int aprilsam_amd_resident_end(april_graph_t *graph, april_graph_cholesky_param_t *param) { return asam::resident_end(graph, param); }
+int aprilsam_amd_level_profile(const april_graph_cholesky_param_t *param, double *out6, int cap_levels) { return asam::level_profile(param, out6, cap_levels); }
 int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls, double *flops, double *bytes, const char **names) {
     return asam::kernel_profile(param, ms, calls, flops, bytes, names);
 }

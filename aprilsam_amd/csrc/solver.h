@@ -58,6 +58,7 @@ int resident_steps(april_graph_t *g, april_graph_cholesky_param_t *param, int n,
 int resident_sync(april_graph_t *g, april_graph_cholesky_param_t *param);
 double resident_chi2(april_graph_t *g);
 int resident_end(april_graph_t *g, april_graph_cholesky_param_t *param);
+int level_profile(const april_graph_cholesky_param_t *param, double *out, int cap_levels);
 int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls, double *flops, double *bytes, const char **names);
 void drop_context(const april_graph_cholesky_param_t *p);
 void drop_graph_pack(const april_graph_t *g);

@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak; HBM peak from MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_TAG = "r03"              # profiles/<tag>_pmc_*.json written by tools/profile_round.sh <tag>
+PMC_TAG = "r04"              # profiles/<tag>_pmc_*.json written by tools/profile_round.sh <tag>
 FLOP_KERNELS = {"k_front_small", "k_front_medium", "k_syrk_big", "k_panel_big", "k_diag_big"}
 
 
@@ -54,11 +54,15 @@ def kernel_profile(lib, p):
     return [dict(name=names[k].decode(), ms=ms[k], calls=calls[k], flops=fl[k], bytes=by[k]) for k in range(n)]
 
 
+HASHED_SOURCES = ("kernels.hip.h", "solver.hip.cpp", "solver_pack.inc.h", "solver_context.inc.h", "solver_inc.inc.h", "solver_calls.inc.h",
+                  "solver_resident.inc.h", "solver_shard.inc.h")      # the kernels and the host runtime that launches them
+
+
 def source_hash():
     """sha256[:16] of the kernel + host runtime sources: profiles/*_pmc_*.json carry the hash they were collected with"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("kernels.hip.h", "solver.hip.cpp"):
+    for f in HASHED_SOURCES:
         h.update(open(os.path.join(ROOT, "aprilsam_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -149,6 +153,42 @@ def big_front_rooflines(prof, iters, pmc_file):
                     e["cus_busy_on_average"] = c.get("cus_busy_on_average")
         e["counter_source"] = src
         out.append(e)
+    return out
+
+
+def level_profile(lib, p, iters):
+    """per level of the assembly tree, from the instrumented pass (aprilsam_amd_level_profile): ms per iteration of the
+    factorisation and of the back substitution, fronts, fronts on the multi-workgroup path, widest own part, GFLOP"""
+    lv = (C.c_double * (6 * 64))()
+    lib.dll.aprilsam_amd_level_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+    nl = lib.dll.aprilsam_amd_level_profile(C.cast(p.ptr, C.c_void_p), lv, 64)
+    return [dict(level=l, factor_ms=lv[6 * l] / iters, backsolve_ms=lv[6 * l + 1] / iters, fronts=int(lv[6 * l + 2]), multi_workgroup=int(lv[6 * l + 3]),
+                 widest_own_columns=int(lv[6 * l + 4]), gflop=lv[6 * l + 5] / 1e9) for l in range(max(nl, 0))]
+
+
+def modelled_scaling_from_level_times(levels, other_ms, total_ms, chain_us_per_outer_block=80.0):
+    """What the MEASURED single-GPU level times say about G GPUs (a model, labelled as such: this builder has one GPU).
+    A level with n fronts takes t on one GPU; on G GPUs with the fronts spread over the ranks it takes t / min(n, G) -- but never
+    less than the dependent chain of its widest front: one outer block of 128 columns after the other, ~80 us each (k_block_chain
+    + k_block_solve + the wide update's launch; profiles/r03_chain_times_lattice100k.txt), which no amount of GPUs shortens.
+    `owner`: a front whose rank range spans several ranks runs on ONE of them (what is built); `spread`: its trailing updates
+    are shared by all ranks of its range, its panel chain is not (what SURVEY 8(e)'s block-cyclic top fronts could reach at
+    best, before any communication).  Everything that is not a level kernel (linearisation, state update) is divided by G."""
+    out = {}
+    for G in (2, 4, 8):
+        t_owner = t_spread = 0.0
+        for L in levels:
+            n = max(1, L["fronts"])
+            chain = 1e-3 * chain_us_per_outer_block * ((L["widest_own_columns"] + 127) // 128) if L["multi_workgroup"] else 0.0
+            both = L["factor_ms"] + L["backsolve_ms"]
+            t_owner += max(chain, both / min(n, G))
+            t_spread += max(chain, both / G)
+        t_owner += other_ms / G; t_spread += other_ms / G
+        out[f"G{G}"] = {"ms_top_fronts_on_one_owner": t_owner, "speedup_top_fronts_on_one_owner": total_ms / t_owner,
+                        "ms_top_fronts_spread": t_spread, "speedup_top_fronts_spread": total_ms / t_spread}
+    out["note"] = ("model from the measured per-level times of THIS single-GPU run (no communication, perfect balance below the top): "
+                   "t_level / min(fronts, G), floored by the widest front's chain of 128-column outer blocks; 'spread' = the best a "
+                   "distribution of the multi-rank fronts' updates could do")
     return out
 
 
@@ -281,7 +321,12 @@ def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iter
         chi.append(lib.dll.aprilsam_amd_resident_chi2(g.ptr))
         lib.dll.aprilsam_amd_resident_steps(g.ptr, p.ptr, 2, 1)
         lp = kernel_profile(lib, p); st = p.stats()
+        levels = level_profile(lib, p, 2)
         fac_ms = sum(k["ms"] / 2 for k in lp if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big"))
+        lev_ms = sum(L["factor_ms"] + L["backsolve_ms"] for L in levels)
+        all_ms = sum(k["ms"] / 2 for k in lp)
+        res["levels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in L.items()} for L in levels]
+        res["modelled_scaling_from_level_times"] = modelled_scaling_from_level_times(levels, max(all_ms - lev_ms, 0.0), all_ms)
         res.update(parallelism="single GPU", kernels_ms_per_step={k["name"]: round(k["ms"] / 2, 3) for k in lp},
                    nnz_L=st["nnz_L"], sum_cj2=st["flops_factor"], fronts=st["n_fronts"], levels=st["n_levels"],
                    max_front_rows=st["max_front_rows"], factor_tflops=st["flops_factor"] / (1e-3 * fac_ms) / 1e12,
@@ -342,7 +387,7 @@ def headline_into_config(out):
         cfg["lattice100k"]["kernels_ms_per_step"] = l100["kernels_ms_per_step"]
     l1m = out.get("lattice1m", {})
     cfg["lattice1m"] = pick(l1m, ("ms_per_step", "n_gpus", "factor_tflops", "parallelism", "chi2_relerr_vs_single_gpu", "modelled_critical_path",
-                                  "comm_bytes_per_iteration", "error"))
+                                  "comm_bytes_per_iteration", "modelled_scaling_from_level_times", "error"))
     if isinstance(l1m.get("comm"), dict):
         cfg["lattice1m"]["comm"] = pick(l1m["comm"], ("transport", "ncclCommCount", "ncclCommUserRank", "rccl_version", "librccl"))
     if isinstance(l1m.get("kernels_ms_per_step"), dict):

@@ -346,6 +346,10 @@ int    aprilsam_amd_resident_end(april_graph_t *graph, april_graph_cholesky_para
  * number of kernels filled; names[k] points at static strings. */
 int aprilsam_amd_kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls,
                                 double *flops, double *bytes, const char **names);
+/* The same passes per LEVEL of the assembly tree: out6[6 * l + ...] = {ms factorisation (assembly included), ms back substitution,
+ * fronts, fronts on the multi-workgroup path, widest own part (scalar columns), sum c_j^2 flops of the level}; a multi-level
+ * launch is booked on its first level.  Returns the number of levels (fills at most cap_levels). */
+int aprilsam_amd_level_profile(const april_graph_cholesky_param_t *param, double *out6, int cap_levels);
 
 /* ---- multi-GPU: nested-dissection subtree sharding, one process per GPU -------
  * The reference has no counterpart (it is sequential); a C host drives a sharded solve through the same graph / param

@@ -22,3 +22,10 @@ n = lib.dll.aprilsam_amd_kernel_profile(p.ptr, ms, calls, fl, by, names)
 print({names[k].decode(): round(ms[k] / 2, 3) for k in range(n)})
 tf = sum(ms[k] for k in range(n) if names[k].decode() in ("k_front_small", "k_assemble_big", "k_panel_big", "k_syrk_big")) / 2
 print(f"factor {tf:.1f} ms -> {st['flops_factor']/tf/1e9:.2f} TFLOP/s")
+lv = (C.c_double * (6 * 64))()
+lib.dll.aprilsam_amd_level_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+nl = lib.dll.aprilsam_amd_level_profile(C.cast(p.ptr, C.c_void_p), lv, 64)
+print("level: fronts (multi-workgroup)  widest own part  GFLOP   factor ms   back-substitution ms      [per iteration]")
+for l in range(nl):
+    up, dn, nf, nb, mx, fl = (lv[6 * l + k] for k in range(6))
+    print(f"  {l:2d}: {int(nf):7d} ({int(nb):3d})  {int(mx):6d}  {fl / 1e9:9.3f}  {up / 2:9.3f}  {dn / 2:9.3f}")

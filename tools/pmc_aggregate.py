@@ -92,6 +92,6 @@ for sub, label, out in (("pmc_mfma", "python tools/lattice_big.py 316 2   (100k-
                "kernels": per}, open(os.path.join(dst, out), "w"), indent=1)
     print("wrote", out)
 for f in ("ubench_mfma_f64.txt", "ubench_valu_lat.txt", "ubench_launch_lat.txt", "chain_times_lattice100k.txt", "inc_profile.txt", "inc_trace_medians.txt", "inc_slowest.txt",
-          "first_call.txt", "plan_time.txt"):
+          "first_call.txt", "plan_time.txt", "inc_steps.txt", "inc_steps_no_update.txt", "batch_only.txt", "stats_lattice.log", "stats_lattice1m.log"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}")); print("wrote", f"{tag}_{f}")

@@ -4,7 +4,7 @@
 # Outputs under gpurun_out/prof_<tag>/ ; tools/pmc_aggregate.py turns them into the files kept in profiles/.
 # Counter passes are separate runs (one --pmc set each, no trace domains besides the kernel trace), without hipGraph
 # replay (counter collection over graph replays does not terminate on ROCm 7.2) and each under its own timeout.
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -39,6 +39,10 @@ python $ROOT/tools/trace_medians.py $OUT/stats_inc > $OUT/inc_trace_medians.txt 
 # ... its host-side split and the phases inside k_inc_one (wall-clock stamps), where its time goes, the first call of a process, the planner
 APRILSAM_AMD_INC_PROFILE=2 timeout 100 python $ROOT/tools/inc_demo.py 3500 > $OUT/inc_profile.txt 2>&1
 timeout 100 python $ROOT/tools/inc_slowest.py > $OUT/inc_slowest.txt 2>&1
+# ... per class of step (fronts regenerated / updated), with and without the low-rank updates; the demo's --batch_update_only mode
+APRILSAM_AMD_INC_PROFILE=1 timeout 100 python $ROOT/tools/inc_steps.py 3500 > $OUT/inc_steps.txt 2>&1
+APRILSAM_AMD_INC_UPDATE=0 timeout 100 python $ROOT/tools/inc_steps.py 3500 > $OUT/inc_steps_no_update.txt 2>&1
+timeout 100 python $ROOT/tools/batch_only.py 1200 > $OUT/batch_only.txt 2>&1
 timeout 100 python $ROOT/tools/first_call.py --count-first > $OUT/first_call.txt 2>&1
 APRILSAM_AMD_PLAN_PROFILE=1 timeout 100 python $ROOT/tools/plan_time.py > $OUT/plan_time.txt 2>&1
 timeout 60 $ROOT/tools/ubench/launch_lat > $OUT/ubench_launch_lat.txt 2>&1
