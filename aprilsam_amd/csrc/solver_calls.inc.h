@@ -173,11 +173,15 @@ void batch_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
 struct IncProf {
     bool on = false; double acc[8] = { 0 }; long long n = 0;
     std::vector<std::array<float, 7>> steps;          // per step: the six phases + total (medians at exit)
+    std::vector<float> regen;                         // ... and the fronts it regenerated (-1: re-planned)
     std::vector<std::array<float, 4>> kst;            // =2: phases of k_inc_one in us (patches, linearise, fronts, back substitution)
     std::vector<std::array<float, 10>> fst;           //     ... and of its last front
     IncProf() { const char *e = getenv("APRILSAM_AMD_INC_PROFILE"); on = e && (*e == '1' || *e == '2'); }
     ~IncProf() {
         if (!on || !n) return;
+        if (const char *path = getenv("APRILSAM_AMD_INC_PROFILE_DUMP")) {       // per step: 7 floats (the six phases + total) and the fronts it regenerated, for tools/inc_phases.py
+            if (FILE *fp = fopen(path, "wb")) { for (size_t i = 0; i < steps.size(); i++) { fwrite(steps[i].data(), 4, 7, fp); const float r = i < regen.size() ? regen[i] : -1.f; fwrite(&r, 4, 1, fp); } fclose(fp); }
+        }
         fprintf(stderr, "aprilsam_amd inc profile over %lld steps (ms/step): pack %.4f model %.4f upload %.4f plan+enqueue %.4f d2h+sync %.4f writeback %.4f | total %.4f\n",
                 n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n, (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5]) / n);
         double med[7];
@@ -345,6 +349,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         const double te = now_ms();
         g_incprof.acc[4] += tp5 - tp4; g_incprof.acc[5] += te - tp5; g_incprof.n++;
         g_incprof.steps.push_back({ (float)(tp1 - t0), (float)(tp2 - tp1), (float)(tp3 - tp2), (float)(tp4 - tp3), (float)(tp5 - tp4), (float)(te - tp5), (float)(te - t0) });
+        g_incprof.regen.push_back(reused ? (float)c.st.reserved0 : -1.f);
     }
     // aprilsam.c:557-559, the wall-clock rule: "this step took longer than a third of a batch step -> start over".  The
     // reference sets start_over = INT_MAX BEFORE its solver call, whose walk then adds one per pose that newly crossed the

@@ -141,12 +141,16 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_ol
     }
     gp.fptr.resize(Fg); gp.g2p.resize((size_t)Fg + 1);
     int F = gp.g2p[from];
+    {   // the pinned mirrors are sized ONCE for everything this call appends (a pinned reallocation costs a quarter of a millisecond)
+        size_t total = (size_t)F;
+        for (int i = from; i < Fg; i++) { const int k = fs[i]->nnodes; total += k >= 3 ? (size_t)k * (k - 1) / 2 : 1; }
+        gp.h_fa.need(total, true); gp.h_fb.need(total, true); gp.h_z.need(3 * total, true); gp.h_W.need(9 * total, true);
+        gp.is_host.resize(total, 0); gp.p2g.resize(total); gp.vslot.resize(total);
+    }
     for (int i = from; i < Fg; i++) {
         const april_graph_factor_t *f = fs[i];
         gp.fptr[i] = f;
         classify(f, i);
-        gp.h_fa.need((size_t)F + ne, true); gp.h_fb.need((size_t)F + ne, true); gp.h_z.need((size_t)3 * (F + ne), true); gp.h_W.need((size_t)9 * (F + ne), true);
-        gp.is_host.resize((size_t)F + ne, 0); gp.p2g.resize((size_t)F + ne); gp.vslot.resize((size_t)F + ne);
         for (int e = 0; e < ne; e++, F++) {
             gp.h_fa.p[F] = ents[e].a; gp.h_fb.p[F] = ents[e].b; gp.is_host[F] = ents[e].host; gp.p2g[F] = i;
             gp.vslot[F] = (unsigned)ents[e].slots | ((unsigned)ents[e].carry << 16);
