@@ -634,7 +634,7 @@ def main():
                   "total_ms": float(ms.sum()), "mean_ms": float(ms.mean()), "median_ms": float(np.median(ms)), "p99_ms": float(np.percentile(ms, 99)),
                   "final_chi2": float(r["chi2"][-1]),
                   "note": "batch_extend: the plan is kept while the graph only grows (appended poses become tail fronts, every front is "
-                          "re-factorised); full re-plan every 8 tail fronts"}
+                          "re-factorised); full re-plan every 3 x 24 appended poses (extend_tail_fronts)"}
             if os.path.exists(REFLIB) and not a.no_cpu_baseline:
                 rr = harness.run_demo(host.SolverLib(REFLIB), datasets.m3500_arrays(), batch_update_only=True, max_poses=npos)
                 rms = rr["ms"][1:]

@@ -296,6 +296,16 @@ void aprilsam_amd_clear_error(void);
  *                       rows); 0 = every dirty front is re-assembled and re-factorised in full
  *   "inc_inline"        1 (default): a small step's patches (<= 24 ranges, <= 2 KiB) travel in the kernel arguments; 0 = always read
  *                       from pinned host memory by the kernel
+ *   "inc_update"        1 (default, needs inc_multi): a new factor between an old pose and a recent one UPDATES the factor of every front
+ *                       on the old pose's root path (three vectors per factor travelling up the assembly tree; the last tail front is
+ *                       still re-factorised) instead of re-assembling and re-factorising those fronts; stats.inc_fronts_updated counts
+ *                       them.  0 = round-3 behaviour
+ *   "inc_tail_solve"    1 (default, needs inc_tail): when every pose the step's walk visits lies among the last 8 poses, the back
+ *                       substitution and the state update run inside the same single-workgroup launch, on the trailing columns alone
+ *   "inc_lazy_states"   1 (default): an incremental step whose walk is partial compares only the node objects it reads (the poses of its new
+ *                       factors, the visited poses, the new poses) with the library's state mirrors; 0 = every node object on every step
+ *   "inc_replan_tall"   1 (default): when a front of a plan made of single-workgroup fronts only has collected so many loop-closure rows that
+ *                       it no longer fits the LDS, the step re-plans; 0 = it takes the multi-workgroup path from then on
  *   "tail_poses"        own poses per tail front of the incremental path (default 28, at least 8)
  *   "persist"           1 (default): the top levels of the elimination tree -- as many as hold at most "persist_max_fronts"
  *                       (default 240) single-workgroup fronts -- run as ONE launch per sweep, fronts synchronised by
