@@ -448,7 +448,12 @@ struct Dissector {
     // candidates: slot 3 = the BFS level structure (the longest job: first), the others geometric bisections
     int candidate_jobs(size_t n, CandJob (&jobs)[8]) const {
         static const int T_DIRS = getenv("APRILSAM_AMD_ND_DIRS") ? atoi(getenv("APRILSAM_AMD_ND_DIRS")) : 8;
-        static const int T_MORE = getenv("APRILSAM_AMD_ND_MORE") ? atoi(getenv("APRILSAM_AMD_ND_MORE")) : 0;      // region size (x leaf) above which 4 more directions are tried
+        // region size (x leaf) above which 4 more directions are tried.  Round 4: 256 (regions of more than 4 096 poses) instead of never --
+        // the principal axis of a square region is whatever the noise makes it: on the 1 000 x 1 000 lattice it came out 22 degrees off
+        // the axes, none of {0, 45, 90} degrees from it was a lattice direction, and the root separator was a DIAGONAL (1 397 poses
+        // instead of 1 000; every level below likewise): with eight directions the top of the tree is what a lattice deserves --
+        // sum c_j^2 811 -> 535 GFLOP at 1 M poses, 18.7 -> 17.0 at 100 k; M3500 (3 500 poses) keeps its plan
+        static const int T_MORE = getenv("APRILSAM_AMD_ND_MORE") ? atoi(getenv("APRILSAM_AMD_ND_MORE")) : 256;
         int nj = 0;
         jobs[nj++] = { 3, 0.0 };
         jobs[nj++] = { 0, 0.0 };                                         // principal axis
