@@ -250,8 +250,11 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (!c.model.valid) c.model.batch(c.batch_nodes, c.batch_factors, gp.h_fa.p, gp.h_fb.p);      // lazily, after a batch step
     c.model.inc_begin(N, F, gp.h_fa.p, gp.h_fb.p);
     std::vector<RefModel::Visit> &visits = c.visits;
-    c.model.plan_visit(visits);                      // structural: which poses the reference's solve_node touches
     const bool partial = c.model.naffected <= 5;     // aprilsam.c:755: otherwise the whole tree is walked
+    // structural: which poses the reference's solve_node touches.  A partial walk's list decides what the GPU back-substitutes: now.  A
+    // full walk's list (every pose, in the reference's tree order: 14 us on M3500) is only needed when the numbers are back: it is
+    // made while the GPU works, below
+    if (partial) c.model.plan_visit(visits); else visits.clear();
     const double tp0b = now_ms();
     // states: the pinned mirrors follow the node objects; the fast path patches / loads the device copies from its first kernels.
     // A partial walk reads only the poses of the new factors and the visited ones: only those are looked at (pack_states_some)
@@ -292,6 +295,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         inc_prepare(c);
     }
     c.inc_F = F; c.inc_N = N; c.same_topo_batches = 0;
+    if (!partial) c.model.plan_visit(visits);        // (the full walk's list, under the GPU's work)
     if (!reused) c.st.inc_fronts_updated = 0;
     c.st.inc_replanned = reused ? 0 : 1; c.st.inc_old_old_cross = c.model.old_old_cross;      // (include/aprilsam_amd.h: what the caller is told)
     const double tp4 = now_ms();
