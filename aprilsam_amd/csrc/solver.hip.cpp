@@ -63,6 +63,8 @@ static void load_env_options() {
         v = g_opt.trust_factor_cache; envd("APRILSAM_AMD_TRUST_FACTOR_CACHE", &v); g_opt.trust_factor_cache = (int)v;
         v = g_opt.small_lds_kb; envd("APRILSAM_AMD_SMALL_LDS_KB", &v); g_opt.small_lds_kb = (int)v;
         v = g_opt.syrk128_rows; envd("APRILSAM_AMD_SYRK128_ROWS", &v); g_opt.syrk128_rows = (int)v;
+        v = g_opt.syrk_xcd_order; envd("APRILSAM_AMD_SYRK_XCD_ORDER", &v); g_opt.syrk_xcd_order = (int)v;
+        v = g_opt.syrk_variant; envd("APRILSAM_AMD_SYRK_VARIANT", &v); g_opt.syrk_variant = (int)v;
         v = g_opt.panel_mode; envd("APRILSAM_AMD_PANEL_MODE", &v); g_opt.panel_mode = (int)v;
         v = g_opt.small_threads; envd("APRILSAM_AMD_SMALL_THREADS", &v); g_opt.small_threads = (int)v;
         v = g_opt.tp_fronts; envd("APRILSAM_AMD_TP_FRONTS", &v); g_opt.tp_fronts = (int)v;
@@ -256,6 +258,17 @@ int selftest() {
             if (nt < 1 || (long long)nt * PANEL_ROWS < below || (nt > 1 && (long long)(nt - 1) * PANEL_ROWS >= below)) return -31;
         }
     }
+    // (3b) the XCD-aware tile order of the wide updates is a bijection onto the same trapezoid
+    for (int ntr = 1; ntr <= 75; ntr += (ntr < 20 ? 1 : 7))
+        for (int ntc = 1; ntc <= ntr; ntc += (ntc < 20 ? 1 : 5)) {
+            const int nt = ntc * ntr - ntc * (ntc - 1) / 2;
+            std::vector<char> seen((size_t)ntr * ntc, 0);
+            for (int l = 0; l < nt; l++) {
+                int ti = -1, tj = -1;
+                trapezoid_tile_xcd(l, nt, ntr, ntc, &ti, &tj);
+                if (tj < 0 || tj >= ntc || ti < tj || ti >= ntr || seen[(size_t)tj * ntr + ti]++) return -35;
+            }
+        }
     // (4) LDS budgets: a front classified "full" also fits as "panel", and the work-list region is what the kernel carves
     for (int nw : { 4, 8, 16 })
         for (int R = 6; R < 400; R += 7)
@@ -286,6 +299,8 @@ int api_set_option(const char *name, double v) {
     else if (k == "small_lds_kb") g_opt.small_lds_kb = (int)v;
     else if (k == "medium_lds_kb") {}                 // accepted for compatibility: the single-workgroup L2 kernel is gone (panel mode)
     else if (k == "syrk128_rows") g_opt.syrk128_rows = (int)v;
+    else if (k == "syrk_xcd_order") g_opt.syrk_xcd_order = (int)v;
+    else if (k == "syrk_variant") g_opt.syrk_variant = (int)v;
     else if (k == "panel_mode") g_opt.panel_mode = (int)v;
     else if (k == "small_threads") g_opt.small_threads = (int)v;
     else if (k == "tp_fronts") g_opt.tp_fronts = (int)v;

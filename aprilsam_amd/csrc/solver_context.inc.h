@@ -593,8 +593,10 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
     auto wide = [&](const Launch &w, int k, int mode, hipStream_t st) {
         if (w.tile == TILE2)
             hipLaunchKernelGGL(k_syrk_big128, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
+        else if (g_opt.syrk_variant == 1)
+            hipLaunchKernelGGL(k_syrk_big_w2, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode | (std::max(0, g_opt.syrk_xcd_order) << SYRK_MODE_XCD_SHIFT), c.d_pool.p);
         else
-            hipLaunchKernelGGL(k_syrk_big, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
+            hipLaunchKernelGGL(k_syrk_big, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode | (std::max(0, g_opt.syrk_xcd_order) << SYRK_MODE_XCD_SHIFT), c.d_pool.p);
     };
     if (la && !c.s2) {        // lowest priority: its big kernels must not delay the one-workgroup kernels of the chain
         int lo = 0, hi = 0;
@@ -667,7 +669,7 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
         }
         if (sy.grid > 0 && !ll) {
             tic(K_SYRK_BIG);
-            hipLaunchKernelGGL(k_syrk_big, dim3(sy.grid), dim3(TPB), 0, s, c.dp, tab + sy.list_off, tab + sy.pre_off, sy.n, (int)k, (int)k + 1, 0, c.d_pool.p);
+            hipLaunchKernelGGL(k_syrk_big_w2, dim3(sy.grid), dim3(TPB), 0, s, c.dp, tab + sy.list_off, tab + sy.pre_off, sy.n, (int)k, (int)k + 1, 0, c.d_pool.p);
             toc();
         }
         if (!la) {

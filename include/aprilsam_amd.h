@@ -274,6 +274,10 @@ void aprilsam_amd_clear_error(void);
  *   "small_threads", "tp_threads"  workgroup size of the single-workgroup front kernel (256 / 512 / 1024) on
  *                       latency-bound levels (default 1024) and on throughput levels (default 512)
  *   "syrk128_rows"      trailing updates at least this tall use the LDS-staged 128x128 MFMA kernel (default off)
+ *   "syrk_variant"      wide trailing updates: 0 (default) = 5 waves per SIMD (2 K-steps of operands in flight, C read after the K
+ *                       loop); 1 = the round-2/3 kernel (8 K-steps, C up front, 2 waves per SIMD)
+ *   "syrk_xcd_order"    wide trailing updates of at least this many 64x64 tiles use the XCD-aware tile order (default 512 = one
+ *                       round of workgroups; 0 = never, 1 = always)
  *   "batch_extend"      1 (default): april_graph_cholesky on a graph that only GREW since the last plan keeps the plan -- the
  *                       appended poses become tail fronts, every front is re-factorised (batch semantics) -- instead of a new
  *                       ordering + symbolic analysis per call; once more than "extend_tail_fronts" (default 3) x 24 poses have been

@@ -60,5 +60,15 @@ int main() {
         n = (double)grid * 256 * iters * 8 * 2;
         printf("v_fma_f64 x8 acc, %d WG/CU: %.3f ms  %.2f TFLOP/s\n", wpc, ms, n / ms / 1e9);
     }
+    // occupancy x accumulator sweep (round 4): what the wide-update kernel can hope for at 3-5 waves per SIMD
+    for (int wpc = 1; wpc <= 6; wpc++) {
+        const int grid = cus * wpc;
+        float m1 = timeit([&] { hipLaunchKernelGGL(k_mfma<1>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0, 1.0, (long long *)nullptr); });
+        float m2 = timeit([&] { hipLaunchKernelGGL(k_mfma<2>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0, 1.0, (long long *)nullptr); });
+        float m4 = timeit([&] { hipLaunchKernelGGL(k_mfma<4>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0, 1.0, (long long *)nullptr); });
+        float m8 = timeit([&] { hipLaunchKernelGGL(k_mfma<8>, dim3(grid), dim3(256), 0, 0, out, iters / 2, 1.0, 1.0, (long long *)nullptr); });
+        const double n = (double)grid * 4 * iters * 2048 / 1e9;
+        printf("sweep %d waves/SIMD: acc x1 %.1f  x2 %.1f  x4 %.1f  x8 %.1f TFLOP/s\n", wpc, n / m1, n * 2 / m2, n * 4 / m4, n * 4 / m8);
+    }
     return 0;
 }
