@@ -26,6 +26,7 @@ struct Options {
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
     int syrk_xcd_order = 512;     // wide trailing updates of at least this many tiles (one round of workgroups is 512): tile order in which every XCD works on 8 x 8 blocks of tiles (kernels.hip.h: trapezoid_tile_xcd); 0 = never
     int syrk_variant = 0;         // wide trailing updates: 0 = 2 K-steps of operands in flight, C read after the K loop, 5 waves per SIMD; 1 = rounds 2-3: 8 K-steps, C up front, 2 waves
+    int schur_first = 40;         // panel-mode small fronts with at least this many update blocks: update columns assembled after the Schur product has been stored into them (0 = never; M3500's fronts stay below: on its latency path the second assembly pass costs more than the zero fill it saves)
     int small_threads = 1024;     // workgroup size of k_front_small (256 / 512 / 1024) on latency-bound levels ...
     int tp_threads = 512;         // ... and on throughput levels (>= tp_fronts fronts)
     int tp_fronts = 1000;         // levels with at least this many fronts are "throughput levels" ...

@@ -65,6 +65,7 @@ static void load_env_options() {
         v = g_opt.syrk128_rows; envd("APRILSAM_AMD_SYRK128_ROWS", &v); g_opt.syrk128_rows = (int)v;
         v = g_opt.syrk_xcd_order; envd("APRILSAM_AMD_SYRK_XCD_ORDER", &v); g_opt.syrk_xcd_order = (int)v;
         v = g_opt.syrk_variant; envd("APRILSAM_AMD_SYRK_VARIANT", &v); g_opt.syrk_variant = (int)v;
+        v = g_opt.schur_first; envd("APRILSAM_AMD_SCHUR_FIRST", &v); g_opt.schur_first = (int)v;
         v = g_opt.panel_mode; envd("APRILSAM_AMD_PANEL_MODE", &v); g_opt.panel_mode = (int)v;
         v = g_opt.small_threads; envd("APRILSAM_AMD_SMALL_THREADS", &v); g_opt.small_threads = (int)v;
         v = g_opt.tp_fronts; envd("APRILSAM_AMD_TP_FRONTS", &v); g_opt.tp_fronts = (int)v;
@@ -301,6 +302,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "syrk128_rows") g_opt.syrk128_rows = (int)v;
     else if (k == "syrk_xcd_order") g_opt.syrk_xcd_order = (int)v;
     else if (k == "syrk_variant") g_opt.syrk_variant = (int)v;
+    else if (k == "schur_first") g_opt.schur_first = (int)v;
     else if (k == "panel_mode") g_opt.panel_mode = (int)v;
     else if (k == "small_threads") g_opt.small_threads = (int)v;
     else if (k == "tp_fronts") g_opt.tp_fronts = (int)v;

@@ -434,6 +434,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.inc.o_rows = (long long)o_rows; c.inc.o_rel = (long long)o_rel;
     d.lambda = c.d_lambda.p;
     d.prof = nullptr; d.prof_mode = 0;
+    d.schur_first_nub = std::max(0, g_opt.schur_first);
     if (getenv("APRILSAM_AMD_KPROF")) { c.d_prof.need((size_t)PROF_SLOTS * P.nF); HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)8 * PROF_SLOTS * P.nF, s)); d.prof = c.d_prof.p; d.prof_mode = atoi(getenv("APRILSAM_AMD_KPROF")) >= 2 ? atoi(getenv("APRILSAM_AMD_KPROF")) : 1; }
     c.d_swap.need((size_t)P.F + INC_FACT_); c.d_pos.need((size_t)P.N + INC_NODES_);
     HIPCHECK(hipMemcpyAsync(c.d_swap.p, P.fac_swap.data(), P.F, hipMemcpyHostToDevice, s));
