@@ -275,6 +275,18 @@ struct Dissector {
         }
     }
 
+    // The component just found by bfs() (visit order in `order`, already labelled Lc) in ASCENDING vertex order, as every split is
+    // computed on it.  Regions are kept ascending (the root is 0 .. N-1, parts are filtered from ascending components), so a connected
+    // region -- nearly every one -- is its own component, and a large part of a region is a filter pass over it: no sort
+    // (std::sort of the root's 3 500 vertices was 0.1 ms of the 0.5 ms its level takes, on the calling thread).
+    std::vector<int> ascending_component(const std::vector<int> &verts, bool verts_ascending, const std::vector<int> &order, int Lc) {
+        if (verts_ascending && order.size() == verts.size()) return verts;
+        std::vector<int> comp;
+        if (verts_ascending && order.size() * 8 > verts.size()) { comp.reserve(order.size()); for (int v : verts) if (lab(v) == Lc) comp.push_back(v); }
+        else { comp = order; std::sort(comp.begin(), comp.end()); }
+        return comp;
+    }
+
     struct alignas(128) Split { std::vector<int> S, P0, P1; double cost = 1e300; bool ok = false; };      // (own cache lines: candidates are filled side by side)
     Split cand_[8], ref_out_;   // candidates of the region being split / result of a refinement (buffers reused from region to region)
 
@@ -426,15 +438,14 @@ struct Dissector {
             if (deferred && item.verts.size() <= defer_below) { deferred->push_back(std::move(item)); continue; }
             int L = new_label();
             for (int v : item.verts) set_lab(v, L);
+            const bool asc = std::is_sorted(item.verts.begin(), item.verts.end());
             // connected components of the region
             for (int s : item.verts) {
                 if (lab(s) != L) continue;
                 bfs(s, L, order);
-                std::vector<int> comp(order);
-                for (int v : comp) dist[v] = -1;
                 int Lc = new_label();
-                for (int v : comp) set_lab(v, Lc);
-                std::sort(comp.begin(), comp.end());
+                for (int v : order) { dist[v] = -1; set_lab(v, Lc); }
+                std::vector<int> comp = ascending_component(item.verts, asc, order, Lc);
                 handle(comp, Lc, item.parent, stack);
             }
         }
@@ -531,14 +542,13 @@ struct Dissector {
         std::vector<int> &order = comp_order_;
         const int L = new_label();
         for (int v : verts) set_lab(v, L);
+        const bool asc = std::is_sorted(verts.begin(), verts.end());
         for (int s : verts) {
             if (lab(s) != L) continue;
             bfs(s, L, order);
-            std::vector<int> comp(order);
-            for (int v : comp) dist[v] = -1;
             const int Lc = new_label();
-            for (int v : comp) set_lab(v, Lc);
-            std::sort(comp.begin(), comp.end());
+            for (int v : order) { dist[v] = -1; set_lab(v, Lc); }
+            std::vector<int> comp = ascending_component(verts, asc, order, Lc);
             out.comps.emplace_back();
             CompResult &cr = out.comps.back();
             Split *best = (int)comp.size() <= leaf ? nullptr : best_split(comp, Lc);
@@ -553,20 +563,22 @@ struct Dissector {
     // labels are this evaluator's; the candidates run on per-thread helpers that share its labels.
     struct CompWork { std::vector<int> comp; int L = 0; CompResult *out = nullptr; Split cand[8]; Split *best = nullptr, *second = nullptr; double second_cost0 = 0; };
     void process_regions(const std::vector<const std::vector<int> *> &regions, const std::vector<RegionResult *> &outs) {
+        static const bool prof = getenv("APRILSAM_AMD_PLAN_PROFILE") != nullptr;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tp0 = prof ? now() : 0;
         std::vector<std::unique_ptr<CompWork>> work;
         std::vector<int> &order = comp_order_;
         for (size_t r = 0; r < regions.size(); r++) {
             const std::vector<int> &verts = *regions[r];
             const int L = new_label();
             for (int v : verts) set_lab(v, L);
+            const bool asc = std::is_sorted(verts.begin(), verts.end());
             for (int s : verts) {
                 if (lab(s) != L) continue;
                 bfs(s, L, order);
-                std::vector<int> comp(order);
-                for (int v : comp) dist[v] = -1;
                 const int Lc = new_label();
-                for (int v : comp) set_lab(v, Lc);
-                std::sort(comp.begin(), comp.end());
+                for (int v : order) { dist[v] = -1; set_lab(v, Lc); }
+                std::vector<int> comp = ascending_component(verts, asc, order, Lc);
                 outs[r]->comps.emplace_back();
                 CompResult &cr = outs[r]->comps.back();
                 if ((int)comp.size() <= leaf) { cr.leaf = true; cr.verts = std::move(comp); continue; }
@@ -584,7 +596,9 @@ struct Dissector {
         std::vector<J> jobs;
         for (auto &w : work) { CandJob cj[8]; const int nj = candidate_jobs(w->comp.size(), cj); for (int k = 0; k < nj; k++) jobs.push_back({ w.get(), cj[k] }); }
         std::stable_sort(jobs.begin(), jobs.end(), [](const J &a, const J &b) { return (a.jb.slot == 3) > (b.jb.slot == 3); });      // the long ones first
+        const double tp1 = prof ? now() : 0;
         pool->run((int)jobs.size(), [&](int k, int who) { mine(who).eval_candidate(jobs[k].w->comp, jobs[k].w->L, jobs[k].jb, jobs[k].w->cand); });
+        const double tp2 = prof ? now() : 0;
         struct R { CompWork *w; Split *c; };
         std::vector<R> refs;
         for (auto &w : work) {
@@ -595,6 +609,8 @@ struct Dissector {
             }
         }
         pool->run((int)refs.size(), [&](int k, int who) { mine(who).refine_split(refs[k].w->comp, refs[k].w->L, refs[k].c); });
+        const double tp3 = prof ? now() : 0;
+        struct Fin { bool on; double a, b, c, d; size_t n; std::function<double()> now_; ~Fin() { if (on) fprintf(stderr, "aprilsam_amd dissection: %zu region(s): components %.3f candidates %.3f refinement %.3f results %.3f ms\n", n, b - a, c - b, d - c, now_() - d); } } fin_{ prof, tp0, tp1, tp2, tp3, regions.size(), now };
         for (auto &w : work) {
             Split *best = w->best, *second = w->second;
             if (best && (int)w->comp.size() > refine_min() * leaf) {
