@@ -99,6 +99,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     // (aprilsam.c:628).  The walk also pulls the node objects into the cache for the second half below.
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
     for (int i = N - 1; i >= 0; i--) { april_graph_node_t *n = ns[i]; n->UID = i; memcpy(n->l_point, gp.h_state.p + (size_t)3 * i, 24); }
+    c.reap_retired();                                  // (graphs of earlier plans: destroyed under the GPU's work)
     HIPCHECK(hipStreamSynchronize(gp.stream));
     const double t4 = now_ms();
     check_bad(c);

@@ -128,15 +128,18 @@ struct Context {
     // writes new states / dx / pivot flag back to pinned mirrors -- one graph launch + one stream sync per call
     hipGraphExec_t gexec_api = nullptr;
     const void *api_key[7] = {};
+    int api_key_runs = 0;                          // calls seen with this key: the first one runs without a graph (below)
+    // captured graphs that are no longer current: hipGraphExecDestroy takes 0.24 ms on this stack, so they are destroyed while the
+    // GPU works on a step (reap_retired), not on the way to the next plan
+    std::vector<hipGraphExec_t> retired;
+    void retire(hipGraphExec_t &g) { if (g) { retired.push_back(g); g = nullptr; } }
+    void reap_retired() { for (hipGraphExec_t g : retired) (void)hipGraphExecDestroy(g); retired.clear(); }
     double lambda_val = -1; int lambda_N = -1;     // what d_lambda currently holds (uniform batch value), -1: unknown
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
         d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release();
         h_done.release(); h_kstamp.release(); d_prof.release(); d_upd.release(); d_wbuf.release(); d_flags.release(); d_flevel.release(); d_perm.release(); d_solve_tab.release(); d_dinv.release(); d_bsb_far.release(); d_bsb_flags.release();
-        if (gexec) (void)hipGraphExecDestroy(gexec);
-        gexec = nullptr;
-        if (gexec_api) (void)hipGraphExecDestroy(gexec_api);
-        gexec_api = nullptr;
+        retire(gexec); retire(gexec_api); reap_retired();
         if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
         have_events = false;
         for (auto &e : k_ev) (void)hipEventDestroy(e);
@@ -380,8 +383,9 @@ struct ShardLayout { std::vector<long long> off; std::vector<char> ghost; long l
 // upload the symbolic plan and build the per-level launch tables
 static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = nullptr) {
     const Plan &P = c.plan;
-    if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
-    if (c.gexec_api) { (void)hipGraphExecDestroy(c.gexec_api); c.gexec_api = nullptr; }
+    const bool uprof = getenv("APRILSAM_AMD_PLAN_PROFILE") != nullptr;
+    const double u0 = uprof ? now_ms() : 0;
+    c.retire(c.gexec); c.retire(c.gexec_api); c.api_key_runs = 0;
     c.lambda_N = -1;
     // ---- descriptors + index arrays ----------------------------------------------------------------------------
     std::vector<FrontDesc> &fd = c.inc.fd; fd.assign(P.nF, FrontDesc());
@@ -405,6 +409,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
         }
         r.rel_begin = 0; r.pad = cfr;                  // rel_begin patched below; pad keeps the child's front id
     }
+    const double u1 = uprof ? now_ms() : 0;
     // slack for the incremental path is only reserved once the param has been used incrementally (a 3-node tutorial graph
     // solved in batch mode should not cost hundreds of MB of HBM); the first incremental call then re-plans once
     const bool inc = c.want_inc;
@@ -442,6 +447,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.d_perm.need((size_t)P.N + INC_NODES_);
     HIPCHECK(hipMemcpyAsync(c.d_perm.p, P.perm.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
 
+    const double u2 = uprof ? now_ms() : 0;
     // ---- launch tables -------------------------------------------------------------------------------------
     std::vector<int> tab;
     c.levels.assign(P.nLevels, LevelPlan());
@@ -496,8 +502,10 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     c.d_tab.need(tab.size() + INC_TAB_);
     c.inc.tab_used = (long long)tab.size();
     c.base_tab = tab;
+    const double u3 = uprof ? now_ms() : 0;
     HIPCHECK(hipMemcpyAsync(c.d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
     HIPCHECK(hipStreamSynchronize(s));      // host vectors above go out of scope
+    const double u4 = uprof ? now_ms() : 0;
 
     const long long pool_slack = inc ? std::max<long long>(INC_POOL_MIN, P.pool_doubles / 4) : 0;
     const long long pool_doubles = lay ? lay->pool_doubles : P.pool_doubles;
@@ -516,6 +524,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
         for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, diag_doubles(c.levels[l].n_big, c.levels[l].n_diag_slots));
         c.d_diag.need(mx);
     }
+    if (uprof) fprintf(stderr, "aprilsam_amd upload: graphs destroyed + descriptors %.3f, index arrays + copies %.3f, launch tables %.3f, last copies + sync %.3f, pools %.3f ms\n", u1 - u0, u2 - u1, u3 - u2, u4 - u3, now_ms() - u4);
     c.st.n_fronts = P.nF; c.st.n_levels = P.nLevels; c.st.max_front_rows = P.max_rows;
     c.st.nnz_L = P.nnzL; c.st.flops_factor = P.flops; c.st.bytes_fronts = 8.0 * (double)pool_doubles;
 }
@@ -809,15 +818,17 @@ static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp
     if (io_host) {
         if (g_opt.use_graph && !timing && gp.host_idx.empty()) {
             const void *key[7] = { gp.d_state.p, gp.h_state.p, gp.h_lp.p, gp.h_dx.p, c.h_bad.p, (const void *)(size_t)gp.N, (const void *)(size_t)gp.serial };
-            if (!c.gexec_api || memcmp(key, c.api_key, sizeof(key)) != 0) {
-                if (c.gexec_api) { (void)hipGraphExecDestroy(c.gexec_api); c.gexec_api = nullptr; }
+            // A graph is worth its capture, instantiation and destruction (0.3 ms together) only if the configuration comes back:
+            // the first call with a new key -- every fall-back of an incremental run, every cold call -- enqueues its kernels directly.
+            if (memcmp(key, c.api_key, sizeof(key)) != 0) { c.retire(c.gexec_api); memcpy(c.api_key, key, sizeof(key)); c.api_key_runs = 0; }
+            if (c.api_key_runs++ == 0) { enqueue_numeric(c, gp, s, nullptr, false, false, true); return; }
+            if (!c.gexec_api) {
                 hipGraph_t graph = nullptr;
                 HIPCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 enqueue_numeric(c, gp, s, nullptr, false, false, true);
                 HIPCHECK(hipStreamEndCapture(s, &graph));
                 HIPCHECK(hipGraphInstantiate(&c.gexec_api, graph, nullptr, nullptr, 0));
                 HIPCHECK(hipGraphDestroy(graph));
-                memcpy(c.api_key, key, sizeof(key));
             }
             HIPCHECK(hipGraphLaunch(c.gexec_api, s));
         } else {
@@ -827,7 +838,7 @@ static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp
     }
     if (g_opt.use_graph && !timing && !unary_at_lp && gp.host_idx.empty()) {   // (host-evaluated factors: staging buffers may move)
         if (!c.gexec || c.gexec_key != (const void *)gp.d_state.p || c.gexec_serial != gp.serial) {
-            if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
+            c.retire(c.gexec);
             hipGraph_t graph = nullptr;
             HIPCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             enqueue_numeric(c, gp, s, nullptr);
