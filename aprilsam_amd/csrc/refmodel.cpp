@@ -87,18 +87,33 @@ std::vector<int> ref_min_degree_order(int N, const std::vector<std::vector<int>>
         eb[e_off[i] + e_len[i]++] = e;
     };
     std::vector<int> mark(N, 0); int tok = 0;
-    // the reference's lists are FIFOs (zarray remove at 0, add at the end): a vector with a head index does the same without the two
-    // allocations every std::deque costs (thousands of lists per call: a list that is re-created for a key without a hash put is a new one)
-    struct Fifo { std::vector<int> v; size_t head = 0; bool empty() const { return head == v.size(); } int front() const { return v[head]; } void pop_front() { head++; } void push_back(int x) { v.push_back(x); } };
-    std::vector<Fifo> lists;
-    std::unordered_map<uint32_t, int> registry;          // key -> list (only lists created with a hash put)
+    // the reference's lists are FIFOs (zarray remove at 0, add at the end) and a pose may sit in several of them at once (phase 1
+    // below adds the unmarked ones again and again): entries {pose, next} in one arena, a head and a tail per list -- no allocation
+    // per list (there are thousands: a list that is re-created for a key without a hash put is a new one)
+    std::vector<int> ent_node, ent_next, l_head, l_tail;
+    ent_node.reserve((size_t)4 * N); ent_next.reserve((size_t)4 * N); l_head.reserve(N); l_tail.reserve(N);
+    auto new_list = [&]() { l_head.push_back(-1); l_tail.push_back(-1); return (int)l_head.size() - 1; };
+    auto list_push = [&](int l, int node) {
+        const int e = (int)ent_node.size();
+        ent_node.push_back(node); ent_next.push_back(-1);
+        if (l_tail[l] >= 0) ent_next[l_tail[l]] = e; else l_head[l] = e;
+        l_tail[l] = e;
+    };
+    auto list_pop = [&](int l) {                         // (the list is not empty)
+        const int e = l_head[l], node = ent_node[e];
+        l_head[l] = ent_next[e];
+        if (l_head[l] < 0) l_tail[l] = -1;
+        return node;
+    };
+    // key -> list (only lists created with a hash put).  Keys are degrees plus at most 2 (N - 1) (phase 1): a table, not a hash map
+    size_t maxdeg = 0; for (int i = 0; i < N; i++) maxdeg = std::max(maxdeg, adj[i].size());
+    std::vector<int> registry((size_t)3 * N + maxdeg + 8, -1);
     RefHeap heap;
     auto add_registered = [&](uint32_t key, int node) {
-        auto it = registry.find(key);
-        if (it != registry.end()) { lists[it->second].push_back(node); return; }
-        lists.emplace_back(); lists.back().push_back(node);
-        registry[key] = (int)lists.size() - 1;
-        heap.add((int)lists.size() - 1, (float)(-1.0 * key));
+        if (registry[key] >= 0) { list_push(registry[key], node); return; }
+        const int l = new_list(); list_push(l, node);
+        registry[key] = l;
+        heap.add(l, (float)(-1.0 * key));
     };
     std::vector<char> set_marker(N, 0);
     if (N > 0) {
@@ -159,16 +174,15 @@ std::vector<int> ref_min_degree_order(int N, const std::vector<std::vector<int>>
     };
     int li; float v;
     while (heap.pop(&li, &v)) {                           // :1128-1238
-        while (!lists[li].empty()) {
-            const int b = lists[li].front(); lists[li].pop_front();
+        while (l_head[li] >= 0) {
+            const int b = list_pop(li);
             if (gone[b]) continue;
             const int deg = degree(b);
             if ((float)deg <= -v) { ordering.push_back(b); eliminate(b); }      // its neighbours become a clique (:1150-1222)
             else {                                                      // :1224-1235 (no hash put for a new list)
                 const uint32_t key = (uint32_t)deg;
-                auto it = registry.find(key);
-                if (it != registry.end()) lists[it->second].push_back(b);
-                else { lists.emplace_back(); lists.back().push_back(b); heap.add((int)lists.size() - 1, (float)(-1.0 * key)); }
+                if (registry[key] >= 0) list_push(registry[key], b);
+                else { const int l = new_list(); list_push(l, b); heap.add(l, (float)(-1.0 * key)); }
             }
         }
     }
