@@ -26,6 +26,7 @@ struct Options {
     int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
     int syrk_xcd_order = 512;     // wide trailing updates of at least this many tiles (one round of workgroups is 512): tile order in which every XCD works on 8 x 8 blocks of tiles (kernels.hip.h: trapezoid_tile_xcd); 0 = never
     int syrk_variant = 0;         // wide trailing updates: 0 = 2 K-steps of operands in flight, C read after the K loop, 5 waves per SIMD; 1 = rounds 2-3: 8 K-steps, C up front, 2 waves
+    int syrk_small_tiles = 320;   // wide trailing updates of fewer 64 x 64 tiles than this (a quarter of a round of workgroups) use 32 x 32 tiles; 0 = never.  Measured on the 100 k lattice: k_syrk_big 0.664 (never) / 0.633 (320) / 0.648 (640) / 0.676 (1280) ms -- such a launch is 27 us of start / end latencies whatever its tiles
     int schur_first = 40;         // panel-mode small fronts with at least this many update blocks: update columns assembled after the Schur product has been stored into them (0 = never; M3500's fronts stay below: on its latency path the second assembly pass costs more than the zero fill it saves)
     int small_threads = 1024;     // workgroup size of k_front_small (256 / 512 / 1024) on latency-bound levels ...
     int tp_threads = 512;         // ... and on throughput levels (>= tp_fronts fronts)

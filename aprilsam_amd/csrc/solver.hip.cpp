@@ -66,6 +66,7 @@ static void load_env_options() {
         v = g_opt.syrk_xcd_order; envd("APRILSAM_AMD_SYRK_XCD_ORDER", &v); g_opt.syrk_xcd_order = (int)v;
         v = g_opt.syrk_variant; envd("APRILSAM_AMD_SYRK_VARIANT", &v); g_opt.syrk_variant = (int)v;
         v = g_opt.schur_first; envd("APRILSAM_AMD_SCHUR_FIRST", &v); g_opt.schur_first = (int)v;
+        v = g_opt.syrk_small_tiles; envd("APRILSAM_AMD_SYRK_SMALL_TILES", &v); g_opt.syrk_small_tiles = (int)v;
         v = g_opt.panel_mode; envd("APRILSAM_AMD_PANEL_MODE", &v); g_opt.panel_mode = (int)v;
         v = g_opt.small_threads; envd("APRILSAM_AMD_SMALL_THREADS", &v); g_opt.small_threads = (int)v;
         v = g_opt.tp_fronts; envd("APRILSAM_AMD_TP_FRONTS", &v); g_opt.tp_fronts = (int)v;
@@ -229,8 +230,8 @@ int selftest() {
             }
             return 0;
         };
-        for (int variant = 0; variant < 4; variant++) {          // wide update whole / split for look-ahead, both tile sizes
-            const int tile = (variant & 1) ? TILE2 : TILE; const bool split = variant >= 2;
+        for (int variant = 0; variant < 6; variant++) {          // wide update whole / split for look-ahead, all three tile sizes
+            const int tile = variant >= 4 ? TILE / 2 : ((variant & 1) ? TILE2 : TILE); const bool split = variant >= 2 && variant < 4;
             std::fill(applied.begin(), applied.end(), 0); std::fill(ksum.begin(), ksum.end(), 0);
             for (int s = 0; s < steps; s++) {
                 // when panel s is factored, each of its columns j must carry exactly the columns k < s*NB
@@ -303,6 +304,7 @@ int api_set_option(const char *name, double v) {
     else if (k == "syrk_xcd_order") g_opt.syrk_xcd_order = (int)v;
     else if (k == "syrk_variant") g_opt.syrk_variant = (int)v;
     else if (k == "schur_first") g_opt.schur_first = (int)v;
+    else if (k == "syrk_small_tiles") g_opt.syrk_small_tiles = (int)v;
     else if (k == "panel_mode") g_opt.panel_mode = (int)v;
     else if (k == "small_threads") g_opt.small_threads = (int)v;
     else if (k == "tp_fronts") g_opt.tp_fronts = (int)v;

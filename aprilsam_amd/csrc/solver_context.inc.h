@@ -348,7 +348,12 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
             // wide trailing matrices go to the LDS-staged 128 x 128 kernel (decided per launch on the largest front)
             int span = 0;
             for (int i = 0; i < active(s_lo); i++) { SyrkRange r = syrk_range(rows(big[i]), cols(big[i]), 3 * nsb_of(big[i]), s_lo, sidx + 1, 1); if (r.ntr > 0) span = std::max(span, rows(big[i]) - 2 - r.col_lo); }
-            const int tile = span >= g_opt.syrk128_rows ? TILE2 : TILE;
+            int tile = span >= g_opt.syrk128_rows ? TILE2 : TILE;
+            if (tile == TILE && g_opt.syrk_small_tiles > 0) {         // few tiles: 32 x 32 ones (k_syrk_big32)
+                long long nt64 = 0;
+                for (int i = 0; i < active(s_lo); i++) nt64 += syrk_tiles(rows(big[i]), cols(big[i]), 3 * nsb_of(big[i]), s_lo, sidx + 1, 1, TILE);
+                if (nt64 < g_opt.syrk_small_tiles) tile = TILE / 2;
+            }
             L.syrkw.push_back(make(active(s_lo), [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, sidx + 1, 1, tile); }));
             L.syrkw.back().tile = tile;
             L.syrka.push_back(make(active(s_lo), [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, sidx + 1, 2); }));
@@ -601,7 +606,9 @@ template <class Tic, class Toc>
 static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, bool la = false, const int *tab = nullptr) {
     if (!tab) tab = c.d_tab.p;
     auto wide = [&](const Launch &w, int k, int mode, hipStream_t st) {
-        if (w.tile == TILE2)
+        if (w.tile == TILE / 2)
+            hipLaunchKernelGGL(k_syrk_big32, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode | (std::max(0, g_opt.syrk_xcd_order) << SYRK_MODE_XCD_SHIFT), c.d_pool.p);
+        else if (w.tile == TILE2)
             hipLaunchKernelGGL(k_syrk_big128, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
         else if (g_opt.syrk_variant == 1)
             hipLaunchKernelGGL(k_syrk_big_w2, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode | (std::max(0, g_opt.syrk_xcd_order) << SYRK_MODE_XCD_SHIFT), c.d_pool.p);

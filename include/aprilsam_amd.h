@@ -277,6 +277,8 @@ void aprilsam_amd_clear_error(void);
  *   "schur_first"       small fronts in panel mode with at least this many update blocks store the Schur product into their update
  *                       columns first and add the factor blocks / children's update blocks afterwards (no zero fill, no atomics
  *                       for the product); default 40, 0 = never
+ *   "syrk_small_tiles"  wide trailing updates of fewer 64x64 tiles than this use 32x32 tiles (four times the workgroups, a quarter of
+ *                       the K loop each); default 320 = a quarter of a round of workgroups, 0 = never
  *   "syrk_variant"      wide trailing updates: 0 (default) = 5 waves per SIMD (2 K-steps of operands in flight, C read after the K
  *                       loop); 1 = the round-2/3 kernel (8 K-steps, C up front, 2 waves per SIMD)
  *   "syrk_xcd_order"    wide trailing updates of at least this many 64x64 tiles use the XCD-aware tile order (default 512 = one

@@ -80,7 +80,7 @@ def test_tutorial_batch_mode_matches_reference_golden(lib):
 
 
 @pytest.mark.parametrize("opts", [dict(small_lds_kb=0), dict(small_lds_kb=48), dict(small_lds_kb=156), dict(panel_mode=0, small_lds_kb=64),
-                                  dict(small_threads=256), dict(small_threads=512), dict(tp_fronts=1, tp_lds_kb=8), dict(lookahead=1, small_lds_kb=0), dict(lookahead=1, small_lds_kb=0, use_graph=0), dict(syrk128_rows=64, small_lds_kb=0), dict(schur_first=1), dict(schur_first=1, small_lds_kb=48), dict(schur_first=1, persist=0, use_graph=0), dict(schur_first=8, leaf_nodes=40), dict(schur_first=0), dict(syrk_variant=1, small_lds_kb=0), dict(syrk_xcd_order=1, small_lds_kb=0), dict(syrk_xcd_order=1, syrk_variant=1, small_lds_kb=0, use_graph=0), dict(syrk_xcd_order=0, small_lds_kb=0),
+                                  dict(small_threads=256), dict(small_threads=512), dict(tp_fronts=1, tp_lds_kb=8), dict(lookahead=1, small_lds_kb=0), dict(lookahead=1, small_lds_kb=0, use_graph=0), dict(syrk128_rows=64, small_lds_kb=0), dict(schur_first=1), dict(schur_first=1, small_lds_kb=48), dict(schur_first=1, persist=0, use_graph=0), dict(schur_first=8, leaf_nodes=40), dict(schur_first=0), dict(syrk_small_tiles=0, small_lds_kb=0), dict(syrk_small_tiles=1 << 30, small_lds_kb=0), dict(syrk_small_tiles=1 << 30, small_lds_kb=0, lookahead=1, syrk_xcd_order=1), dict(syrk_variant=1, small_lds_kb=0), dict(syrk_xcd_order=1, small_lds_kb=0), dict(syrk_xcd_order=1, syrk_variant=1, small_lds_kb=0, use_graph=0), dict(syrk_xcd_order=0, small_lds_kb=0),
                                   dict(block_panels=0, small_lds_kb=0), dict(block_panels=0, small_lds_kb=48), dict(blk_backsolve=0, small_lds_kb=0), dict(tile_assembly=1, small_lds_kb=0), dict(tile_assembly=1, small_lds_kb=48, use_graph=0), dict(tile_assembly=1, small_lds_kb=0, leaf_nodes=64), dict(small_lds_kb=0, leaf_nodes=64), dict(small_lds_kb=0, leaf_nodes=4, use_graph=0),
                                   dict(leaf_nodes=4), dict(leaf_nodes=40), dict(use_graph=0), dict(device_timing=1),
                                   dict(block_factor=0), dict(block_factor=0, panel_mode=0, small_lds_kb=64), dict(fused_panel=0, small_lds_kb=0, block_panels=0),
@@ -92,7 +92,7 @@ def test_every_kernel_path_agrees_with_oracle(lib, oracle, opts):
     instead of the in-register 16-column chain, other workgroup sizes and leaf sizes, the newest poses pinned into the root
     front, no hipGraph, k_linearize with the LDS-staged write-out, no / all-level multi-level launches: same answers"""
     defaults = dict(small_lds_kb=156, panel_mode=1, small_threads=1024, tp_fronts=1000, tp_lds_kb=64, lookahead=0, syrk128_rows=1 << 30, leaf_nodes=16, use_graph=1, device_timing=0,
-                    block_factor=1, fused_panel=1, pin_last=0, trust_factor_cache=0, linearize_staged_min=32768, persist=1, persist_max_fronts=240, wave_backsolve=1, left_panels=1, block_panels=1, blk_backsolve=1, tile_assembly=0, syrk_variant=0, syrk_xcd_order=512, schur_first=40)
+                    block_factor=1, fused_panel=1, pin_last=0, trust_factor_cache=0, linearize_staged_min=32768, persist=1, persist_max_fronts=240, wave_backsolve=1, left_panels=1, block_panels=1, blk_backsolve=1, tile_assembly=0, syrk_variant=0, syrk_xcd_order=512, schur_first=40, syrk_small_tiles=320)
     arr = datasets.random_pose_graph(700, 600, 21)
     oc, ost = oracle.iterate(arr, 2)
     try:
