@@ -95,7 +95,8 @@ def pmc_traffic(pmc, kernel):
 
 
 # rocprofv3 kernel names of the K_BACKSOLVE / K_PANEL_BIG slots (several kernels share a slot)
-PMC_NAMES = {"k_linearize": ("k_linearize_t",), "k_backsolve": ("k_backsolve_blk", "k_backsolve_t", "k_backsolve_w", "k_backsolve_gemv"), "k_panel_big": ("k_block_chain", "k_block_solve", "k_diagpanel_ll")}
+PMC_NAMES = {"k_linearize": ("k_linearize_t",), "k_backsolve": ("k_backsolve_blk", "k_backsolve_t", "k_backsolve_w", "k_backsolve_gemv"), "k_panel_big": ("k_block_chain", "k_block_solve", "k_diagpanel_ll"),
+             "k_syrk_big": ("k_syrk_big", "k_syrk_big32", "k_syrk_big_w2", "k_syrk_big128")}
 
 
 def hbm_rooflines(prof, iters, pmc_file=None, survey_bytes=None):
@@ -144,13 +145,13 @@ def big_front_rooflines(prof, iters, pmc_file):
         e = dict(kernel=name, bound="mfma", achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS,
                  kernel_ms_per_step=k["ms"] / iters, launches_per_step=k["calls"] / iters, algorithmic_flops_per_step=k["flops"])
         if pmc:
-            for n in PMC_NAMES.get(name, (name,)):
-                c = pmc["kernels"].get(n)
-                if c and c.get("SQ_INSTS_VALU_MFMA_MOPS_F64"):
-                    # one v_mfma_f64_16x16x4_f64 = 2048 flops = 4 "MOPS" units of 512: executed (incl. the discarded upper halves of
-                    # diagonal tiles) vs algorithmic, per iteration of the profiled run
-                    e["mfma_executed_flops_per_dispatch"] = 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"] / max(1, c["dispatches"])
-                    e["cus_busy_on_average"] = c.get("cus_busy_on_average")
+            # one v_mfma_f64_16x16x4_f64 = 2048 flops = 4 "MOPS" units of 512: executed (incl. the discarded upper halves of
+            # diagonal tiles) vs algorithmic, over all kernels of the slot (e.g. the 64 x 64 and the 32 x 32 tile forms of the wide update)
+            cs = [pmc["kernels"][n] for n in PMC_NAMES.get(name, (name,)) if pmc["kernels"].get(n, {}).get("SQ_INSTS_VALU_MFMA_MOPS_F64")]
+            if cs:
+                nd = sum(c["dispatches"] for c in cs)
+                e["mfma_executed_flops_per_dispatch"] = 512.0 * sum(c["SQ_INSTS_VALU_MFMA_MOPS_F64"] for c in cs) / max(1, nd)
+                e["cus_busy_on_average"] = round(sum((c.get("cus_busy_on_average") or 0) * c["dispatches"] for c in cs) / max(1, nd), 2)
         e["counter_source"] = src
         out.append(e)
     return out
