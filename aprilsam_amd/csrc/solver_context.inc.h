@@ -102,6 +102,7 @@ struct Context {
     std::vector<RefModel::Visit> visits; std::vector<int> involved;
     std::vector<int> base_tab;                     // host copy of the launch tables of the base plan
     std::vector<int> inc_slot_blk, inc_slot_rhs;   // slots of the factors added since the base plan (3 / 2 per factor)
+    long long pat_serial = -1, pat_topo = -1;      // the pack (serial) and its topo_version at which `pat` last equalled the packed endpoints (prepare_plan)
     RefModel model;                       // the reference's tree / counters (refmodel.cpp), rebuilt lazily after a batch
     PatchList patches;                    // per-step table updates of the incremental fast path
     int batch_factors = 0;                // #factors at the last batch step
@@ -880,9 +881,10 @@ static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g, bool
     const int N = gp.N, F = gp.F;
     bool same = c.have_plan && c.patN == N && (int)c.pat.size() == 2 * F && c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last &&
                 c.plan_persist == launch_table_key() && c.inc.t_first.empty();        // (a plan extended by tail fronts is only driven by inc_fast_step)
-    if (same) {
+    if (same && !(c.pat_serial == gp.serial && c.pat_topo == gp.topo_version)) {      // (same pack, endpoints untouched since the last comparison: nothing to compare)
         for (int i = 0; i < F && same; i++) same = c.pat[2 * i] == gp.h_fa.p[i] && c.pat[2 * i + 1] == gp.h_fb.p[i];
     }
+    c.pat_serial = gp.serial; c.pat_topo = gp.topo_version;       // (c.pat equals the packed endpoints from here on, either way)
     if (same) return true;
     c.pat.resize((size_t)2 * F);
     for (int i = 0; i < F; i++) { c.pat[2 * i] = gp.h_fa.p[i]; c.pat[2 * i + 1] = gp.h_fb.p[i]; }

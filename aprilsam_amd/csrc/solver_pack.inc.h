@@ -19,6 +19,7 @@ struct GraphPack {
     int F_on_device = 0;               // factors already uploaded
     int dirty_lo = 0, dirty_hi = 0;    // packed factors whose z / W changed since the last upload
     long long content_version = 0;     // bumped whenever z / W of a packed factor changed
+    long long topo_version = 0;        // bumped whenever the packed endpoints (h_fa / h_fb, F) changed in any way: a pattern compared equal at (serial, topo_version) still is
     std::vector<char> is_host;         // per factor: evaluated on the host through factor->eval
     std::vector<double> h_upt; DBuf<double> d_upt;   // unary factors: the state they were linearised at when they entered the system (3 per factor)
     int F_cap = 0;                     // device capacity (factors) of d_fa/d_fb/d_z/d_W/d_chi2f
@@ -84,7 +85,7 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_ol
     // (incremental calls only ever look at the factors added since the previous call, aprilsam.c:508-511: first and last packed pointer
     // as a sanity check instead of all of them -- the comparison of 5 000 pointers was a microsecond of every step)
     if (valid && trust) valid = from == 0 || (validate_old ? memcmp(gp.fptr.data(), fs, sizeof(void *) * from) == 0 : (gp.fptr[0] == fs[0] && gp.fptr[from - 1] == fs[from - 1]));
-    auto restart = [&]() { from = 0; gp.F = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; gp.is_host.clear(); gp.p2g.clear(); gp.vslot.clear(); gp.g2p.assign(1, 0); };
+    auto restart = [&]() { gp.topo_version++; from = 0; gp.F = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; gp.is_host.clear(); gp.p2g.clear(); gp.vslot.clear(); gp.g2p.assign(1, 0); };
     if (!valid) restart();
     // one graph factor -> its packed entries (a, b, host flag, node slots of a host pair, what the pair carries)
     struct Ent { int a, b; bool host; unsigned short slots; unsigned char carry; };
@@ -147,6 +148,7 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_ol
         gp.h_fa.need(total, true); gp.h_fb.need(total, true); gp.h_z.need(3 * total, true); gp.h_W.need(9 * total, true);
         gp.is_host.resize(total, 0); gp.p2g.resize(total); gp.vslot.resize(total);
     }
+    if (from < Fg || gp.F != F) gp.topo_version++;
     for (int i = from; i < Fg; i++) {
         const april_graph_factor_t *f = fs[i];
         gp.fptr[i] = f;
