@@ -18,15 +18,16 @@ def _i(a):
     return a.ctypes.data_as(ip)
 
 
-@pytest.mark.parametrize("case", ["m3500", "random0", "random2", "lattice24", "prefix232"])
+@pytest.mark.parametrize("case", ["m3500", "random0", "random1", "random2", "lattice24", "lattice40", "prefix232", "prefix1088"])
 def test_reference_order_and_tree_restated_exactly(lib, reflib, case):
     if case == "m3500":
         arr = datasets.m3500_batch()
-    elif case == "lattice24":
-        arr = lib.lattice_arrays(24)
-    elif case == "prefix232":
-        st, fa, fb, z, W = datasets.m3500_arrays(); m = np.maximum(fa, fb) < 232
-        arr = datasets.with_prior(st[:232], fa[m], fb[m], z[m], W[m])
+    elif case.startswith("lattice"):
+        arr = lib.lattice_arrays(int(case[7:]))
+    elif case.startswith("prefix"):           # the graph of the M3500 demo at one of its batch fall-backs
+        n = int(case[6:])
+        st, fa, fb, z, W = datasets.m3500_arrays(); m = np.maximum(fa, fb) < n
+        arr = datasets.with_prior(st[:n], fa[m], fb[m], z[m], W[m])
     else:
         seed = int(case[-1]); arr = datasets.random_pose_graph(*((12, 6), (80, 60), (400, 350))[seed], seed)
     st, fa, fb = arr[0], np.ascontiguousarray(arr[1], np.int32), np.ascontiguousarray(arr[2], np.int32)
