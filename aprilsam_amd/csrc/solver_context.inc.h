@@ -133,8 +133,8 @@ struct Context {
     // captured graphs that are no longer current: hipGraphExecDestroy takes 0.24 ms on this stack, so they are destroyed while the
     // GPU works on a step (reap_retired), not on the way to the next plan
     std::vector<hipGraphExec_t> retired;
-    void retire(hipGraphExec_t &g) { if (g) { retired.push_back(g); g = nullptr; } }
     void reap_retired() { for (hipGraphExec_t g : retired) (void)hipGraphExecDestroy(g); retired.clear(); }
+    void retire(hipGraphExec_t &g) { if (g) { if (retired.size() >= 8) reap_retired(); retired.push_back(g); g = nullptr; } }      // (bounded: call sequences that never reach a reaping point)
     double lambda_val = -1; int lambda_N = -1;     // what d_lambda currently holds (uniform batch value), -1: unknown
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
