@@ -108,6 +108,26 @@ def test_every_kernel_path_agrees_with_oracle(lib, oracle, opts):
         assert stats["ms_dev_factor"] > 0
 
 
+def test_root_front_ending_in_a_partial_outer_block(lib, oracle):
+    """3 000 poses with 1 800 random loop closures: the root front owns 645 poses = 15 outer blocks of 128 columns + 15 columns, and it
+    is the last array of the front pool.  The row solves and the chain of the wide back substitution used to stage the L blocks of a
+    whole 128-column block -- for that last block 80 columns past the end of the front, i.e. of the pool: a memory fault when the
+    over-read crossed the end of the allocation (round 4: found by a randomised sweep, `tools/stress_random_graphs.py`)"""
+    arr = datasets.random_pose_graph(3000, 1800, 102)
+    oc, ost = oracle.iterate(arr, 2)
+    for opts in (dict(), dict(small_lds_kb=0)):
+        try:
+            for k, v in opts.items():
+                lib.set_option(k, v)
+            chi2, snaps, stats = run_batch(lib, arr, 2)
+        finally:
+            for k in opts:
+                lib.set_option(k, 156)
+        assert stats["max_front_rows"] > 1900
+        assert np.max(np.abs(chi2 - oc) / oc) < 1e-8
+        assert np.max(np.abs(snaps[-1][0] - ost)) < STATE_ATOL
+
+
 def _star(n_leaves, seed):
     """hub 0 connected to every other pose: one separator (the hub), n_leaves children of the root front"""
     rng = np.random.default_rng(seed)
