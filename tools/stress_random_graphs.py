@@ -15,9 +15,10 @@ def run_batch(arr, iters):
         g.cholesky(p); chi2.append(g.chi2())
     st = g.states(); s = p.stats(); p.destroy(); g.destroy()
     return np.array(chi2), st, s
-rng = np.random.default_rng(7)
+base = int(sys.argv[1]) if len(sys.argv) > 1 else 7          # another argument: another set of graphs
+rng = np.random.default_rng(base)
 worst = 0
-cases = [(int(rng.integers(300, 3600)), None, 200 + i) for i in range(24)]
+cases = [(int(rng.integers(300, 3600)), None, 200 * base // 7 + i) for i in range(24)]
 for n, m, seed in cases:
     m = int(n * rng.uniform(0.3, 1.6))
     arr = datasets.random_pose_graph(n, m, seed)
