@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak; HBM peak from MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_TAG = "r04"              # profiles/<tag>_pmc_*.json written by tools/profile_round.sh <tag>
+PMC_TAG = "r05"              # profiles/<tag>_pmc_*.json written by tools/profile_round.sh <tag>
 FLOP_KERNELS = {"k_front_small", "k_front_medium", "k_syrk_big", "k_panel_big", "k_diag_big"}
 
 
@@ -326,7 +326,7 @@ def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iter
         fac_ms = sum(k["ms"] / 2 for k in lp if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big"))
         lev_ms = sum(L["factor_ms"] + L["backsolve_ms"] for L in levels)
         all_ms = sum(k["ms"] / 2 for k in lp)
-        res["levels"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in L.items()} for L in levels]
+        res["level_times"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in L.items()} for L in levels]
         res["modelled_scaling_from_level_times"] = modelled_scaling_from_level_times(levels, max(all_ms - lev_ms, 0.0), all_ms)
         res.update(parallelism="single GPU", kernels_ms_per_step={k["name"]: round(k["ms"] / 2, 3) for k in lp},
                    nnz_L=st["nnz_L"], sum_cj2=st["flops_factor"], fronts=st["n_fronts"], levels=st["n_levels"],
@@ -365,51 +365,105 @@ def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iter
 
 
 def headline_into_config(out):
-    """The driver's record keeps `config` and `roofline` whole and only the NAMES of the other extras, so every number a
-    reader needs to judge the run is copied there: SURVEY.md section 8(d)'s metric (one warm april_graph_cholesky call through
-    the C-ABI, host objects in -> states valid in the host objects), the cold call, config 3 (incremental demo), config 4
-    (100k lattice) and config 5 (1M lattice: ms per iteration at this run's N ranks = the strong-scaling figure, transport as
-    the communication library reports it).  `value` itself stays what the bench contract defines: K steps with the inputs
-    resident in HBM when the timed region starts (a rate that includes the hand-over of host buffers is never `value`)."""
-    def pick(d, keys):
-        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
-    cfg = out["config"]
+    """The driver's record keeps only the SCALAR members of `config` and `roofline` (round 4's nested dicts never reached
+    BENCH_r04.parsed), so every number a reader needs to judge the run is copied there as a flat scalar key:
+      config.api_call_*                 SURVEY.md section 8(d)'s metric (one warm april_graph_cholesky call through the C-ABI)
+      config.lattice100k_*              config 4: ms per iteration, TFLOP/s, chi^2 vs the reference, the reference on THIS host
+      config.lattice1m_*                config 5: ms per iteration at this run's N ranks (strong scaling), transport as RCCL reports it
+      config.inc_*                      config 3: the incremental demo (total / median / schedule / speed-up)
+      config.batch_only_*               the demo's --batch_update_only mode
+      config.l100k_ms_<kernel>, config.l1m_ms_<kernel>     per-kernel ms per iteration
+      roofline.l100k_<kernel>_frac, roofline.l1m_<kernel>_frac, ..._traffic_over_algorithmic
+    `value` itself stays what the bench contract defines: K steps with the inputs resident in HBM when the timed region
+    starts (a rate that includes the hand-over of host buffers is never `value`)."""
+    def scalar(v):
+        return v is None or isinstance(v, (bool, int, float, str))
+    cfg = out["config"]; roof = out["roofline"]
+
+    def put(dst, key, v):
+        if isinstance(v, (list, tuple)) and all(scalar(x) for x in v):          # short vectors: one key per element
+            for i, x in enumerate(v):
+                dst[f"{key}_{i}"] = x
+        elif scalar(v):
+            dst[key] = v
     cfg["value_is"] = "resident loop (bench contract: inputs in HBM when the timed region starts); api_call_* = SURVEY 8(d)'s metric"
     cfg["api_call_it_per_s"] = out.get("value_api_call"); cfg["ms_per_api_call"] = out.get("ms_per_api_call")
     api = out.get("api", {})
     if "default" in api:
         cfg["api_call_warm_ms_median"] = api["default"]["warm_ms_per_call"]; cfg["api_call_cold_ms"] = api.get("cold_ms_per_call")
+    if "error" in api:
+        cfg["api_error"] = api["error"]
     if "cpu_baseline" in out:
         cfg["api_call_speedup_vs_reference_cpu"] = out.get("speedup_vs_cpu_baseline")
+        cfg["resident_speedup_vs_reference_cpu"] = out.get("speedup_resident_vs_cpu_baseline")
+        cfg["cold_call_speedup_vs_reference_cpu"] = out.get("speedup_vs_cpu_baseline_cold_call")
     cfg["factorise_ms"] = out.get("factorise_ms")
+    cfg["parity_chi2_max_relerr_10_iters"] = out.get("parity", {}).get("chi2_max_relerr_10_iters")
+    cfg["parity_max_abs_state_err"] = out.get("parity", {}).get("max_abs_state_err")
+    for k, v in (out.get("kernels_ms_per_step") or {}).items():
+        cfg[f"m3500_ms_{k}"] = v
+    # ---- config 4 -----------------------------------------------------------------------------------------------------
     l100 = out.get("lattice100k", {})
-    cfg["lattice100k"] = pick(l100, ("ms_per_step", "factor_tflops", "chi2_relerr_vs_reference", "speedup_vs_reference_cpu", "error"))
-    if isinstance(l100.get("kernels_ms_per_step"), dict):
-        cfg["lattice100k"]["kernels_ms_per_step"] = l100["kernels_ms_per_step"]
+    for k in ("ms_per_step", "factor_tflops", "chi2_relerr_vs_reference", "speedup_vs_reference_cpu", "sum_cj2", "nnz_L", "fronts", "levels", "error"):
+        if k in l100:
+            put(cfg, f"lattice100k_{k}", l100[k])
+    rc = l100.get("reference_cpu_same_host")
+    if isinstance(rc, dict):
+        cfg["lattice100k_reference_cpu_s_per_iter"] = rc.get("s_per_iter"); cfg["lattice100k_reference_cpu_measured"] = rc.get("measured")
+    for k, v in (l100.get("kernels_ms_per_step") or {}).items():
+        cfg[f"l100k_ms_{k}"] = v
+    # ---- config 5 -----------------------------------------------------------------------------------------------------
     l1m = out.get("lattice1m", {})
-    cfg["lattice1m"] = pick(l1m, ("ms_per_step", "n_gpus", "factor_tflops", "parallelism", "chi2_relerr_vs_single_gpu", "modelled_critical_path",
-                                  "comm_bytes_per_iteration", "modelled_scaling_from_level_times", "error"))
+    for k in ("ms_per_step", "n_gpus", "factor_tflops", "parallelism", "chi2_relerr_vs_single_gpu", "comm_bytes_per_iteration", "sum_cj2",
+              "fronts", "levels", "front_pool_gb_rank0", "schur_slabs_exchanged", "separator_broadcasts", "error"):
+        if k in l1m:
+            put(cfg, f"lattice1m_{k}", l1m[k])
     if isinstance(l1m.get("comm"), dict):
-        cfg["lattice1m"]["comm"] = pick(l1m["comm"], ("transport", "ncclCommCount", "ncclCommUserRank", "rccl_version", "librccl"))
-    if isinstance(l1m.get("kernels_ms_per_step"), dict):
-        cfg["lattice1m"]["kernels_ms_per_step"] = l1m["kernels_ms_per_step"]
+        for k in ("transport", "ncclCommCount", "ncclCommUserRank", "rccl_version", "librccl"):
+            if k in l1m["comm"]:
+                put(cfg, f"lattice1m_{k}", l1m["comm"][k])
+    mcp = l1m.get("modelled_critical_path")
+    if isinstance(mcp, dict):
+        for k, v in mcp.items():
+            put(cfg, f"lattice1m_modelled_critical_path_{k}", v)
+    msc = l1m.get("modelled_scaling_from_level_times")
+    if isinstance(msc, dict):
+        for G in ("G2", "G4", "G8"):
+            if isinstance(msc.get(G), dict):
+                cfg[f"lattice1m_modelled_{G}_speedup_owner"] = msc[G].get("speedup_top_fronts_on_one_owner")
+                cfg[f"lattice1m_modelled_{G}_speedup_spread"] = msc[G].get("speedup_top_fronts_spread")
+    for k, v in (l1m.get("kernels_ms_per_step") or {}).items():
+        cfg[f"l1m_ms_{k}"] = v
+    for tag, blk in (("l100k", l100), ("l1m", l1m)):
+        for L in (blk.get("level_times") if isinstance(blk.get("level_times"), list) else []):
+            if isinstance(L, dict) and "level" in L:
+                cfg[f"{tag}_level{L['level']:02d}_factor_ms"] = L.get("factor_ms"); cfg[f"{tag}_level{L['level']:02d}_backsolve_ms"] = L.get("backsolve_ms")
+    # ---- config 3 and the growing-graph batch mode -----------------------------------------------------------------------
     inc = out.get("m3500_incremental", {})
-    cfg["m3500_incremental"] = pick(inc, ("total_ms", "median_ms", "mean_ms", "p99_ms", "batch_fallbacks", "fallback_schedule_identical",
-                                           "chi2_max_relerr_vs_reference", "speedup_total_vs_reference", "error"))
+    for k in ("total_ms", "median_ms", "mean_ms", "p99_ms", "batch_fallbacks", "fallback_schedule_identical", "chi2_max_relerr_vs_reference",
+              "max_abs_state_err", "speedup_total_vs_reference", "error"):
+        if k in inc:
+            put(cfg, "inc_" + ("fallbacks_identical" if k == "fallback_schedule_identical" else "speedup_vs_reference" if k == "speedup_total_vs_reference" else k), inc[k])
     if isinstance(inc.get("reference_cpu_same_host"), dict):
-        cfg["m3500_incremental"]["reference_cpu"] = pick(inc["reference_cpu_same_host"], ("total_ms", "median_ms"))
-    if isinstance(inc.get("where_the_time_goes"), dict):
-        cfg["m3500_incremental"]["where_the_time_goes"] = inc["where_the_time_goes"]
+        cfg["inc_reference_cpu_total_ms"] = inc["reference_cpu_same_host"].get("total_ms")
+        cfg["inc_reference_cpu_median_ms"] = inc["reference_cpu_same_host"].get("median_ms")
+    for k, v in (inc.get("where_the_time_goes") or {}).items():
+        put(cfg, "inc_" + k.rstrip("_") + ("_above" if k.endswith("_") else ""), v)
     gb = out.get("m3500_batch_update_only", {})
-    cfg["m3500_batch_update_only"] = pick(gb, ("total_ms", "mean_ms", "speedup_total_vs_reference", "error"))
-    # the per-kernel roofline fractions of the lattices ride in `roofline` (kept whole as well)
-    roof = out["roofline"]
-    for tag, blk in (("lattice100k", l100), ("lattice1m", l1m)):
-        rows = []
+    for k in ("total_ms", "mean_ms", "speedup_total_vs_reference", "chi2_max_relerr_vs_reference", "error"):
+        if k in gb:
+            put(cfg, "batch_only_" + ("speedup" if k == "speedup_total_vs_reference" else k), gb[k])
+    # ---- per-kernel roofline fractions of the lattices: flat scalars in `roofline` ----------------------------------------
+    for tag, blk in (("l100k", l100), ("l1m", l1m)):
         for r in (blk.get("roofline") or []) + (blk.get("roofline_hbm") or []):
-            rows.append(pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "kernel_ms_per_step", "traffic_over_algorithmic")))
-        if rows:
-            roof[tag] = rows
+            kn = r.get("kernel")
+            for k in ("frac", "achieved", "unit", "kernel_ms_per_step", "traffic_over_algorithmic", "frac_by_survey_8d_bytes", "cus_busy_on_average"):
+                if k in r and scalar(r[k]):
+                    roof[f"{tag}_{kn}_{k}"] = r[k]
+    # nothing nested may remain in the two objects the driver keeps
+    for d in (cfg, roof):
+        for k in [k for k, v in d.items() if not scalar(v)]:
+            d[k + "_json"] = json.dumps(d.pop(k))
 
 
 def aggregate_value(world, steps, max_dt):
@@ -428,8 +482,10 @@ def main():
     ap.add_argument("--lattice1m-k", type=int, default=1000, help="side of the config-5 lattice (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL; the driver's multi-GPU runs) | gloo (functional test, host staging)")
     ap.add_argument("--one-gpu", action="store_true", help="test mode: every rank uses cuda:0")
-    ap.add_argument("--cpu-lattice100k", action="store_true",
-                    help="also time ONE april_graph_cholesky call of the reference on the 100k lattice on this host (about a minute of CPU)")
+    ap.add_argument("--cpu-lattice100k", action="store_true", help="(default since round 5; kept for old command lines)")
+    ap.add_argument("--no-cpu-lattice100k", action="store_true",
+                    help="do NOT time one april_graph_cholesky call of the reference on the 100k lattice on this host (about half a minute of "
+                         "CPU, single thread); the figure recorded under profiles/ is quoted instead")
     a = ap.parse_args()
 
     import torch
@@ -554,7 +610,9 @@ def main():
             dtl = timed_steps(lib, g, p, ks, lambda x: x, lambda: None)
             lib.dll.aprilsam_amd_resident_steps(g.ptr, p.ptr, 3, 1)
             lp = kernel_profile(lib, p); ls = p.stats()
+            lv100 = level_profile(lib, p, 3)
             out["lattice100k"] = {
+                "level_times": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in L.items()} for L in lv100],
                 "workload": "synthetic 316x316 Manhattan lattice, 99856 poses / 397531 factors (config 4)",
                 "ms_per_step": 1e3 * dtl / ks, "first_call_ms_incl_symbolic": sym_ms,
                 "chi2_0": chi0, "chi2_after_1": chi1,
@@ -572,7 +630,7 @@ def main():
             # about a minute), otherwise the figure recorded by such a run on the GPU box (profiles/, same hardware class)
             from tests.support.oracle_binding import REFLIB
             rec = os.path.join(ROOT, "profiles", PMC_TAG + "_cpu_lattice100k.json")
-            if a.cpu_lattice100k and os.path.exists(REFLIB):
+            if not (a.no_cpu_lattice100k or a.no_cpu_baseline) and os.path.exists(REFLIB):
                 ref = host.SolverLib(REFLIB)
                 g = ref.new_graph(); g.build_from_arrays(*arr); p = ref.new_param()
                 t0 = time.perf_counter(); g.cholesky(p); cpu_s = time.perf_counter() - t0
