@@ -23,30 +23,22 @@ struct Options {
     int inc_replan_tall = 1;      // ... and when a front of an all-single-workgroup plan outgrows the LDS (rows collected from loop closures), the step re-plans instead of taking the multi-launch path from then on
     int inc_update = 1;           // ... and the fronts on the root path of a loop closure take a low-rank UPDATE of their factor (front_update_body) instead of being re-assembled and re-factorised
     int speculate_factors = 1;    // warm batch calls: the pass over the factor objects (edits in place) runs under the GPU's work on the packed copies; an edit voids the run
-    int syrk128_rows = 1 << 30;   // wide trailing updates at least this tall use the LDS-staged 128 x 128 kernel (off: measured 10 % slower than the direct 64 x 64 kernel)
     int syrk_xcd_order = 512;     // wide trailing updates of at least this many tiles (one round of workgroups is 512): tile order in which every XCD works on 8 x 8 blocks of tiles (kernels.hip.h: trapezoid_tile_xcd); 0 = never
-    int syrk_variant = 0;         // wide trailing updates: 0 = 2 K-steps of operands in flight, C read after the K loop, 5 waves per SIMD; 1 = rounds 2-3: 8 K-steps, C up front, 2 waves
     int syrk_small_tiles = 320;   // wide trailing updates of fewer 64 x 64 tiles than this (a quarter of a round of workgroups) use 32 x 32 tiles; 0 = never.  Measured on the 100 k lattice: k_syrk_big 0.664 (never) / 0.633 (320) / 0.648 (640) / 0.676 (1280) ms -- such a launch is 27 us of start / end latencies whatever its tiles
     int schur_first = 40;         // panel-mode small fronts with at least this many update blocks: update columns assembled after the Schur product has been stored into them (0 = never; M3500's fronts stay below: on its latency path the second assembly pass costs more than the zero fill it saves)
     int small_threads = 1024;     // workgroup size of k_front_small (256 / 512 / 1024) on latency-bound levels ...
     int tp_threads = 512;         // ... and on throughput levels (>= tp_fronts fronts)
     int tp_fronts = 1000;         // levels with at least this many fronts are "throughput levels" ...
     int tp_lds_kb = 64;           // ... where only fronts up to this LDS size run fully in LDS (the rest: panel mode, more workgroups per CU)
-    int lookahead = 0;            // 1: wide trailing updates split, next outer block columns first, the rest on a side stream (measured: no gain)
     int pin_last = 0;             // nested dissection keeps the pin_last newest poses out of the dissection: they form the root front ("recent poses last")
     int batch_extend = 1;         // batch calls on a graph that only grew reuse the plan: appended poses become tail fronts, every front is re-factorised
     int extend_tail_fronts = 3;   // ... until the appended poses are this many tail fronts' worth, units of 24 poses (then: full re-plan).  Measured, round 4: demo --batch_update_only 1 500 poses 481 / 388 / 372 / 371 ms at 8 / 4 / 3 / 2; the incremental demo does not care (510 +- 3 %)
     int persist = 1;              // batch path: the top levels of the tree (few small fronts each) as ONE launch per sweep, fronts synchronised by dependency flags
     int persist_max_fronts = 240; // ... as many top levels as fit this many fronts
-    int block_panels = 1;         // big fronts: the four panel steps of a 128-column outer block as two launches (diagonal block in LDS, row solves on the matrix cores)
     int tail_poses = 28;          // incremental path: own poses per tail front (>= 8; measured on the M3500 demo: 24 / 28 / 32 -> 546 / 530 / 528 ms total, median 0.038 / 0.0385 / 0.040 ms)
-    int tile_assembly = 0;        // 1: big fronts assembled window by window in LDS and stored once (measured slower than the default: chunks of block columns, zero fill + L2 atomics)
-    int blk_backsolve = 1;        // wide multi-workgroup fronts: back substitution 128 columns at a time by a chain workgroup + helpers (needs block_panels)
-    int left_panels = 1;          // big fronts: panel steps apply the outer block's earlier panels themselves (no narrow update launches)
+    int blk_backsolve = 1;        // wide multi-workgroup fronts: back substitution 128 columns at a time by a chain workgroup + helpers (0: k_backsolve_gemv + k_backsolve_t)
     int wave_backsolve = 1;       // multi-level back substitution: column-per-lane kernel (0: the per-32-column-block kernel)
     int linearize_staged_min = 32768; // factors per launch from which k_linearize writes its results out through LDS (coalesced stores)
-    int fused_panel = 1;          // big fronts: diagonal block factored inside every row-tile workgroup of the panel kernel (0: k_diag_big + k_panel_big)
-    int block_factor = 1;         // k_front_small: pivot chain of 16 columns at a time in registers (0: per 3x3 pivot through LDS)
     int mem_cap_mb = 0;           // > 0: refuse any single device buffer above this size with ERR_OOM (tests: the out-of-memory path)
     int panel_mode = 1;           // fronts too large for LDS whose own columns fit run in k_front_small's panel mode
 };
@@ -86,5 +78,6 @@ void shard_map(const Plan &P, int world, std::vector<int> &owner, std::vector<ch
 std::vector<long long> shard_critical_path(const Plan &P, int world, const std::vector<int> &owner, const std::vector<char> &top);
 int api_set_device(int d);
 int api_set_option(const char *name, double v);
+int api_get_option(const char *name, double *v);
 
 }  // namespace asam

@@ -51,56 +51,39 @@ static double now_ms() {
 }
 
 Options g_opt;
+// ONE table of the options: name (aprilsam_amd_set_option / aprilsam_amd_get_option; the environment variable is APRILSAM_AMD_<NAME>), member,
+// smallest accepted value, and whether the option is a host-side POLICY that no launch table or captured graph depends on (changing any
+// other option bumps g_opt_epoch: every param re-plans and re-captures on its next call).
+struct OptionDef { const char *name; int Options::*member; int min_value; bool policy; };
+static const OptionDef OPTION_TABLE[] = {
+    { "leaf_nodes", &Options::leaf_nodes, 1, false }, { "deterministic", &Options::deterministic, 0, true }, { "use_graph", &Options::use_graph, 0, true },
+    { "device_timing", &Options::device_timing, 0, true }, { "trust_factor_cache", &Options::trust_factor_cache, 0, true },
+    { "small_lds_kb", &Options::small_lds_kb, 0, false }, { "syrk_xcd_order", &Options::syrk_xcd_order, 0, false },
+    { "schur_first", &Options::schur_first, 0, false }, { "syrk_small_tiles", &Options::syrk_small_tiles, 0, false }, { "panel_mode", &Options::panel_mode, 0, false },
+    { "small_threads", &Options::small_threads, 64, false }, { "tp_fronts", &Options::tp_fronts, 0, false }, { "tp_lds_kb", &Options::tp_lds_kb, 0, false },
+    { "tp_threads", &Options::tp_threads, 64, false }, { "inc_fast", &Options::inc_fast, 0, true }, { "inc_multi", &Options::inc_multi, 0, true },
+    { "inc_one", &Options::inc_one, 0, true }, { "inc_one_up", &Options::inc_one_up, 1, true }, { "inc_one_dn", &Options::inc_one_dn, 1, true },
+    { "inc_one_threads", &Options::inc_one_threads, 64, true }, { "inc_one_spin", &Options::inc_one_spin, 0, true }, { "inc_tail", &Options::inc_tail, 0, false },
+    { "inc_inline", &Options::inc_inline, 0, true }, { "inc_update", &Options::inc_update, 0, true }, { "inc_tail_solve", &Options::inc_tail_solve, 0, true },
+    { "inc_lazy_states", &Options::inc_lazy_states, 0, true }, { "inc_replan_tall", &Options::inc_replan_tall, 0, true },
+    { "speculate_factors", &Options::speculate_factors, 0, true }, { "pin_last", &Options::pin_last, 0, false }, { "persist", &Options::persist, 0, false },
+    { "persist_max_fronts", &Options::persist_max_fronts, 0, false }, { "linearize_staged_min", &Options::linearize_staged_min, 0, false },
+    { "wave_backsolve", &Options::wave_backsolve, 0, false }, { "blk_backsolve", &Options::blk_backsolve, 0, false }, { "tail_poses", &Options::tail_poses, 8, false },
+    { "batch_extend", &Options::batch_extend, 0, true }, { "extend_tail_fronts", &Options::extend_tail_fronts, 0, true }, { "mem_cap_mb", &Options::mem_cap_mb, 0, true },
+};
+static const OptionDef *find_option(const char *name) {
+    for (const OptionDef &d : OPTION_TABLE) if (!strcmp(d.name, name)) return &d;
+    return nullptr;
+}
 static std::once_flag g_opt_once;
 static void load_env_options() {
     std::call_once(g_opt_once, [] {
-        auto envd = [](const char *n, double *v) { const char *s = getenv(n); if (s && *s) *v = atof(s); };
-        double v;
-        v = g_opt.leaf_nodes; envd("APRILSAM_AMD_LEAF_NODES", &v); g_opt.leaf_nodes = (int)v;
-        v = g_opt.deterministic; envd("APRILSAM_AMD_DETERMINISTIC", &v); g_opt.deterministic = (int)v;
-        v = g_opt.use_graph; envd("APRILSAM_AMD_USE_GRAPH", &v); g_opt.use_graph = (int)v;
-        v = g_opt.device_timing; envd("APRILSAM_AMD_DEVICE_TIMING", &v); g_opt.device_timing = (int)v;
-        v = g_opt.trust_factor_cache; envd("APRILSAM_AMD_TRUST_FACTOR_CACHE", &v); g_opt.trust_factor_cache = (int)v;
-        v = g_opt.small_lds_kb; envd("APRILSAM_AMD_SMALL_LDS_KB", &v); g_opt.small_lds_kb = (int)v;
-        v = g_opt.syrk128_rows; envd("APRILSAM_AMD_SYRK128_ROWS", &v); g_opt.syrk128_rows = (int)v;
-        v = g_opt.syrk_xcd_order; envd("APRILSAM_AMD_SYRK_XCD_ORDER", &v); g_opt.syrk_xcd_order = (int)v;
-        v = g_opt.syrk_variant; envd("APRILSAM_AMD_SYRK_VARIANT", &v); g_opt.syrk_variant = (int)v;
-        v = g_opt.schur_first; envd("APRILSAM_AMD_SCHUR_FIRST", &v); g_opt.schur_first = (int)v;
-        v = g_opt.syrk_small_tiles; envd("APRILSAM_AMD_SYRK_SMALL_TILES", &v); g_opt.syrk_small_tiles = (int)v;
-        v = g_opt.panel_mode; envd("APRILSAM_AMD_PANEL_MODE", &v); g_opt.panel_mode = (int)v;
-        v = g_opt.small_threads; envd("APRILSAM_AMD_SMALL_THREADS", &v); g_opt.small_threads = (int)v;
-        v = g_opt.tp_fronts; envd("APRILSAM_AMD_TP_FRONTS", &v); g_opt.tp_fronts = (int)v;
-        v = g_opt.tp_lds_kb; envd("APRILSAM_AMD_TP_LDS_KB", &v); g_opt.tp_lds_kb = (int)v;
-        v = g_opt.tp_threads; envd("APRILSAM_AMD_TP_THREADS", &v); g_opt.tp_threads = (int)v;
-        v = g_opt.lookahead; envd("APRILSAM_AMD_LOOKAHEAD", &v); g_opt.lookahead = (int)v;
-        v = g_opt.inc_fast; envd("APRILSAM_AMD_INC_FAST", &v); g_opt.inc_fast = (int)v;
-        v = g_opt.inc_multi; envd("APRILSAM_AMD_INC_MULTI", &v); g_opt.inc_multi = (int)v;
-        v = g_opt.inc_one; envd("APRILSAM_AMD_INC_ONE", &v); g_opt.inc_one = (int)v;
-        v = g_opt.inc_one_up; envd("APRILSAM_AMD_INC_ONE_UP", &v); g_opt.inc_one_up = (int)v;
-        v = g_opt.inc_one_dn; envd("APRILSAM_AMD_INC_ONE_DN", &v); g_opt.inc_one_dn = (int)v;
-        v = g_opt.inc_one_threads; envd("APRILSAM_AMD_INC_ONE_THREADS", &v); g_opt.inc_one_threads = (int)v;
-        v = g_opt.inc_one_spin; envd("APRILSAM_AMD_INC_ONE_SPIN", &v); g_opt.inc_one_spin = (int)v;
-        v = g_opt.inc_tail; envd("APRILSAM_AMD_INC_TAIL", &v); g_opt.inc_tail = (int)v;
-        v = g_opt.inc_inline; envd("APRILSAM_AMD_INC_INLINE", &v); g_opt.inc_inline = (int)v;
-        v = g_opt.inc_update; envd("APRILSAM_AMD_INC_UPDATE", &v); g_opt.inc_update = (int)v;
-        v = g_opt.inc_tail_solve; envd("APRILSAM_AMD_INC_TAIL_SOLVE", &v); g_opt.inc_tail_solve = (int)v;
-        v = g_opt.inc_lazy_states; envd("APRILSAM_AMD_INC_LAZY_STATES", &v); g_opt.inc_lazy_states = (int)v;
-        v = g_opt.inc_replan_tall; envd("APRILSAM_AMD_INC_REPLAN_TALL", &v); g_opt.inc_replan_tall = (int)v;
-        v = g_opt.speculate_factors; envd("APRILSAM_AMD_SPECULATE_FACTORS", &v); g_opt.speculate_factors = (int)v;
-        v = g_opt.block_factor; envd("APRILSAM_AMD_BLOCK_FACTOR", &v); g_opt.block_factor = (int)v;
-        v = g_opt.fused_panel; envd("APRILSAM_AMD_FUSED_PANEL", &v); g_opt.fused_panel = (int)v;
-        v = g_opt.persist; envd("APRILSAM_AMD_PERSIST", &v); g_opt.persist = (int)v;
-        v = g_opt.persist_max_fronts; envd("APRILSAM_AMD_PERSIST_MAX_FRONTS", &v); g_opt.persist_max_fronts = (int)v;
-        v = g_opt.linearize_staged_min; envd("APRILSAM_AMD_LINEARIZE_STAGED_MIN", &v); g_opt.linearize_staged_min = (int)v;
-        v = g_opt.wave_backsolve; envd("APRILSAM_AMD_WAVE_BACKSOLVE", &v); g_opt.wave_backsolve = (int)v;
-        v = g_opt.left_panels; envd("APRILSAM_AMD_LEFT_PANELS", &v); g_opt.left_panels = (int)v;
-        v = g_opt.block_panels; envd("APRILSAM_AMD_BLOCK_PANELS", &v); g_opt.block_panels = (int)v;
-        v = g_opt.blk_backsolve; envd("APRILSAM_AMD_BLK_BACKSOLVE", &v); g_opt.blk_backsolve = (int)v;
-        v = g_opt.tile_assembly; envd("APRILSAM_AMD_TILE_ASSEMBLY", &v); g_opt.tile_assembly = (int)v;
-        v = g_opt.tail_poses; envd("APRILSAM_AMD_TAIL_POSES", &v); g_opt.tail_poses = std::max(8, (int)v);
-        v = g_opt.batch_extend; envd("APRILSAM_AMD_BATCH_EXTEND", &v); g_opt.batch_extend = (int)v;
-        v = g_opt.extend_tail_fronts; envd("APRILSAM_AMD_EXTEND_TAIL_FRONTS", &v); g_opt.extend_tail_fronts = (int)v;
-        v = g_opt.mem_cap_mb; envd("APRILSAM_AMD_MEM_CAP_MB", &v); g_opt.mem_cap_mb = (int)v;
+        for (const OptionDef &d : OPTION_TABLE) {
+            std::string env = "APRILSAM_AMD_";
+            for (const char *q = d.name; *q; q++) env += (char)toupper((unsigned char)*q);
+            const char *sv = getenv(env.c_str());
+            if (sv && *sv) g_opt.*(d.member) = std::max(d.min_value, (int)atof(sv));
+        }
     });
 }
 
@@ -202,7 +185,7 @@ struct PatchList {
 
 // ------------------------------------------------------------------------------------------------------
 // Host-side consistency checks of the index arithmetic that host launch tables and device kernels share
-// (kernels.hip.h: syrk_range / syrk_tiles / trapezoid decode, upd_packed_offset, panel_tiles).  No GPU needed.
+// (kernels.hip.h: syrk_range / syrk_tiles / trapezoid decode, upd_packed_offset, block_tiles).  No GPU needed.
 // Returns 0, or a negative code naming the first failed check.
 // ------------------------------------------------------------------------------------------------------
 int selftest() {
@@ -214,9 +197,9 @@ int selftest() {
         std::vector<int> applied((size_t)Rv * C, 0);          // number of K columns applied to (i, j), j < C, i < Rv
         std::vector<long long> ksum((size_t)Rv * C, 0);       // sum of applied k (detects duplicates / wrong columns)
         const int steps = (ns + NB - 1) / NB;
-        auto run = [&](int s_lo, int s_hi, int mode, int tile) -> int {
-            const SyrkRange g = syrk_range(R, C, ns, s_lo, s_hi, mode, tile);
-            const int nt = syrk_tiles(R, C, ns, s_lo, s_hi, mode, tile);
+        auto run = [&](int s_lo, int s_hi, int tile) -> int {
+            const SyrkRange g = syrk_range(R, C, ns, s_lo, s_hi, tile);
+            const int nt = syrk_tiles(R, C, ns, s_lo, s_hi, tile);
             if (nt != g.ntc * g.ntr - g.ntc * (g.ntc - 1) / 2) return -11;
             std::vector<char> seen((size_t)std::max(1, g.ntr) * std::max(1, g.ntc), 0);
             for (int l = 0; l < nt; l++) {
@@ -230,20 +213,16 @@ int selftest() {
             }
             return 0;
         };
-        for (int variant = 0; variant < 6; variant++) {          // wide update whole / split for look-ahead, all three tile sizes
-            const int tile = variant >= 4 ? TILE / 2 : ((variant & 1) ? TILE2 : TILE); const bool split = variant >= 2 && variant < 4;
+        for (int tile : { TILE, TILE / 2 }) {          // both tile sizes of the wide update
             std::fill(applied.begin(), applied.end(), 0); std::fill(ksum.begin(), ksum.end(), 0);
-            for (int s = 0; s < steps; s++) {
-                // when panel s is factored, each of its columns j must carry exactly the columns k < s*NB
-                const int k0 = s * NB, k1 = std::min(ns, k0 + NB);
+            for (int o = 0; o * OBP < steps; o++) {
+                // when outer block o is factored, each of its columns j must carry exactly the columns k < o * OBW from the wide updates
+                // (the columns of its own block are applied inside k_block_chain / k_block_solve)
+                const int k0 = o * OBP * NB, k1 = std::min(ns, k0 + OBP * NB);
                 for (int j = k0; j < k1; j++)
                     for (int i = j; i < Rv; i++)
                         if (applied[(size_t)j * Rv + i] != k0 || ksum[(size_t)j * Rv + i] != (long long)k0 * (k0 - 1) / 2) return -13;
-                int rc = run(s, s + 1, 0, TILE); if (rc) return rc;                        // narrow update (always the 64 x 64 kernel)
-                if ((s + 1) % OBP == 0 || s + 1 == steps) {
-                    if (split) { rc = run(s / OBP * OBP, s + 1, 2, TILE); if (rc) return rc; rc = run(s / OBP * OBP, s + 1, 3, tile); if (rc) return rc; }
-                    else { rc = run(s / OBP * OBP, s + 1, 1, tile); if (rc) return rc; }
-                }
+                const int rc = run(o * OBP, (o + 1) * OBP, tile); if (rc) return rc;
             }
             for (int j = ns; j < C; j++)
                 for (int i = j; i < Rv; i++)
@@ -253,12 +232,12 @@ int selftest() {
         long long run_off = 0;
         for (int j = ns; j < C; j++) { if (upd_packed_offset(R, ns, j) != run_off) return -21; run_off += Rv - 3 * (j / 3); }
         if (upd_packed_offset(R, ns, C) != run_off) return -22;
-        // (3) row tiles of the panel kernel cover the rows below every panel exactly once
-        for (int s = 0; s < steps; s++) {
-            const int k0 = s * NB, wdt = std::min(NB, ns - k0), below = Rv - (k0 + wdt);
-            const int nt = panel_tiles(R, ns, s);
-            if (nt < 1 || (long long)nt * PANEL_ROWS < below || (nt > 1 && (long long)(nt - 1) * PANEL_ROWS >= below)) return -31;
-        }
+        // (3) row tiles of the row-solve kernel cover the rows below every outer block exactly once
+        for (int o = 0; o * OBP < steps; o++)
+            for (int rb : { 1, 2 }) {
+                const int c1 = std::min(ns, (o + 1) * OBW), below = Rv - c1, nt = block_tiles(R, ns, o, rb);
+                if ((long long)nt * BLOCK_ROWS * rb < below || (nt > 0 && (long long)(nt - 1) * BLOCK_ROWS * rb >= below)) return -31;
+            }
     }
     // (3b) the XCD-aware tile order of the wide updates is a bijection onto the same trapezoid
     for (int ntr = 1; ntr <= 75; ntr += (ntr < 20 ? 1 : 7))
@@ -291,62 +270,19 @@ int api_set_device(int d) {
 }
 int api_set_option(const char *name, double v) {
     load_env_options();
-    std::string k(name);
-    const Options before = g_opt;
-    if (k == "leaf_nodes") g_opt.leaf_nodes = (int)v;
-    else if (k == "deterministic") g_opt.deterministic = (int)v;
-    else if (k == "use_graph") g_opt.use_graph = (int)v;
-    else if (k == "device_timing") g_opt.device_timing = (int)v;
-    else if (k == "trust_factor_cache") g_opt.trust_factor_cache = (int)v;
-    else if (k == "small_lds_kb") g_opt.small_lds_kb = (int)v;
-    else if (k == "medium_lds_kb") {}                 // accepted for compatibility: the single-workgroup L2 kernel is gone (panel mode)
-    else if (k == "syrk128_rows") g_opt.syrk128_rows = (int)v;
-    else if (k == "syrk_xcd_order") g_opt.syrk_xcd_order = (int)v;
-    else if (k == "syrk_variant") g_opt.syrk_variant = (int)v;
-    else if (k == "schur_first") g_opt.schur_first = (int)v;
-    else if (k == "syrk_small_tiles") g_opt.syrk_small_tiles = (int)v;
-    else if (k == "panel_mode") g_opt.panel_mode = (int)v;
-    else if (k == "small_threads") g_opt.small_threads = (int)v;
-    else if (k == "tp_fronts") g_opt.tp_fronts = (int)v;
-    else if (k == "tp_lds_kb") g_opt.tp_lds_kb = (int)v;
-    else if (k == "tp_threads") g_opt.tp_threads = (int)v;
-    else if (k == "lookahead") g_opt.lookahead = (int)v;
-    else if (k == "inc_fast") g_opt.inc_fast = (int)v;
-    else if (k == "inc_multi") g_opt.inc_multi = (int)v;
-    else if (k == "inc_one") g_opt.inc_one = (int)v;
-    else if (k == "inc_one_up") g_opt.inc_one_up = std::max(1, (int)v);
-    else if (k == "inc_one_dn") g_opt.inc_one_dn = std::max(1, (int)v);
-    else if (k == "inc_one_threads") g_opt.inc_one_threads = (int)v;
-    else if (k == "inc_one_spin") g_opt.inc_one_spin = (int)v;
-    else if (k == "inc_tail") g_opt.inc_tail = (int)v;
-    else if (k == "inc_inline") g_opt.inc_inline = (int)v;
-    else if (k == "inc_update") g_opt.inc_update = (int)v;
-    else if (k == "inc_tail_solve") g_opt.inc_tail_solve = (int)v;
-    else if (k == "inc_lazy_states") g_opt.inc_lazy_states = (int)v;
-    else if (k == "inc_replan_tall") g_opt.inc_replan_tall = (int)v;
-    else if (k == "speculate_factors") g_opt.speculate_factors = (int)v;
-    else if (k == "block_factor") g_opt.block_factor = (int)v;
-    else if (k == "pin_last") g_opt.pin_last = (int)v;
-    else if (k == "fused_panel") g_opt.fused_panel = (int)v;
-    else if (k == "persist") g_opt.persist = (int)v;
-    else if (k == "persist_max_fronts") g_opt.persist_max_fronts = (int)v;
-    else if (k == "linearize_staged_min") g_opt.linearize_staged_min = (int)v;
-    else if (k == "wave_backsolve") g_opt.wave_backsolve = (int)v;
-    else if (k == "left_panels") g_opt.left_panels = (int)v;
-    else if (k == "block_panels") g_opt.block_panels = (int)v;
-    else if (k == "blk_backsolve") g_opt.blk_backsolve = (int)v;
-    else if (k == "tile_assembly") g_opt.tile_assembly = (int)v;
-    else if (k == "tail_poses") g_opt.tail_poses = std::max(8, (int)v);
-    else if (k == "batch_extend") g_opt.batch_extend = (int)v;
-    else if (k == "extend_tail_fronts") g_opt.extend_tail_fronts = (int)v;
-    else if (k == "mem_cap_mb") g_opt.mem_cap_mb = (int)v;
-    else return -1;
-    // host-side policies that no launch table or captured graph depends on
-    static const char *const no_replan[] = { "deterministic", "use_graph", "device_timing", "trust_factor_cache", "inc_fast", "inc_multi", "inc_one", "inc_one_up", "inc_one_dn", "inc_one_threads", "inc_one_spin", "inc_inline", "inc_update", "inc_tail_solve", "inc_lazy_states", "inc_replan_tall", "speculate_factors", "batch_extend",
-                                             "extend_tail_fronts", "mem_cap_mb", "medium_lds_kb" };
-    bool policy = false;
-    for (const char *q : no_replan) policy = policy || k == q;
-    if (!policy && memcmp(&before, &g_opt, sizeof(Options)) != 0) g_opt_epoch++;
+    const OptionDef *d = name ? find_option(name) : nullptr;
+    if (!d) return -1;
+    const int nv = std::max(d->min_value, (int)v);
+    if (g_opt.*(d->member) == nv) return 0;
+    g_opt.*(d->member) = nv;
+    if (!d->policy) g_opt_epoch++;
+    return 0;
+}
+int api_get_option(const char *name, double *v) {
+    load_env_options();
+    const OptionDef *d = name ? find_option(name) : nullptr;
+    if (!d || !v) return -1;
+    *v = (double)(g_opt.*(d->member));
     return 0;
 }
 

@@ -17,7 +17,8 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     bool speculate = g_opt.speculate_factors && !g_opt.trust_factor_cache && !timing0 && c.have_plan && gp.F > 0 && gp.Fg == zsize(g->factors) && gp.N == zsize(g->nodes) &&
                      (int)gp.fptr.size() == gp.Fg && gp.host_idx.empty() && gp.F_on_device == gp.F && gp.dirty_hi <= gp.dirty_lo &&
                      c.patN == gp.N && (int)c.pat.size() == 2 * gp.F && c.inc.t_first.empty() && c.plan_persist == launch_table_key() &&
-                     c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last && g_opt.use_graph && !param->show_timing && !c.no_speculation;
+                     c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last && g_opt.use_graph && !param->show_timing && !c.no_speculation &&
+                     gp.n_asym == 0 && !c.wt_any;       // (asymmetric W: the factors are read first -- their orientation bits depend on what they hold)
     c.no_speculation = false; c.st.reserved1 = 0; c.st.inc_replanned = 0; c.st.inc_old_old_cross = 0;
     if (!speculate) pack_factors(gp, g);
     pack_states(gp, g, false, false);
@@ -30,6 +31,9 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         eval_host_factors(gp, g, 0);
         upload_host_index(gp);
     }
+    // factors with an information matrix that is not symmetric as given: which off-diagonal block the reference accumulates depends on its own
+    // elimination order (aprilsam.c:171); no-op for every other graph
+    const bool model_by_orientation = orient_asymmetric(c, gp);
     const double t1 = now_ms();
     const bool timing = g_opt.device_timing != 0;
     // A graph that only GREW since the plan was made (the reference's demo in --batch_update_only mode, examples/
@@ -40,7 +44,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     bool hybrid = false, reused = false;
     {
         const int patF = (int)c.pat.size() / 2;
-        bool ext = g_opt.batch_extend && !timing && c.have_plan && c.inc.ready && gp.host_idx.empty() && N >= c.patN && F >= patF &&
+        bool ext = g_opt.batch_extend && !timing && c.have_plan && c.inc.ready && gp.host_idx.empty() && gp.n_asym == 0 && !c.wt_any && N >= c.patN && F >= patF &&
                    c.inc_N == c.patN && c.inc_F == patF && c.plan.leaf_nodes == g_opt.leaf_nodes && c.plan_pin == g_opt.pin_last &&
                    c.plan_persist == launch_table_key();
         for (int i = 0; i < patF && ext; i++) ext = c.pat[2 * i] == gp.h_fa.p[i] && c.pat[2 * i + 1] == gp.h_fb.p[i];
@@ -80,6 +84,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     }
     if (!hybrid && !speculate) {
         reused = prepare_plan(c, gp, g);
+        flush_orientation(c, gp.stream);
         t2 = now_ms();
         upload_factors(gp);
         set_lambda(c, gp, param->tikhanov);
@@ -92,8 +97,8 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     }
     // while the GPU works: a param that is used incrementally needs the reference's elimination tree of THIS batch step for
     // its next april_graph_cholesky_inc (refmodel.cpp: the reference's own min-degree order, ~1 ms of integer work on M3500)
-    bool model_ready = false;
-    if (c.used_inc && gp.host_idx.empty()) { c.model.batch(N, F, gp.h_fa.p, gp.h_fb.p); model_ready = true; }      // (not for params that only ever see batch calls)
+    bool model_ready = model_by_orientation;
+    if (c.used_inc && gp.host_idx.empty() && !model_ready) { c.model.batch(N, F, gp.h_fa.p, gp.h_fb.p); model_ready = true; }      // (not for params that only ever see batch calls)
     // ... and the part of the write-back that does not wait for the result: every node is re-linearised at the state it came
     // in with before anything is solved (aprilsam.c:131-135: l_point = state, whatever the factorisation says later), UID = index
     // (aprilsam.c:628).  The walk also pulls the node objects into the cache for the second half below.
@@ -250,6 +255,15 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     const double tp0a = now_ms();
     if (!c.model.valid) c.model.batch(c.batch_nodes, c.batch_factors, gp.h_fa.p, gp.h_fb.p);      // lazily, after a batch step
     c.model.inc_begin(N, F, gp.h_fa.p, gp.h_fb.p);
+    if (gp.n_asym > 0 || c.wt_any) {          // new factors with an asymmetric W: oriented by the positions they enter at (aprilsam.c:393-396,520)
+        if (!gp.host_idx.empty()) fail(ERR_UNSUPPORTED, "factors with an asymmetric information matrix next to factors of foreign types (see orient_asymmetric)");
+        c.wt.resize((size_t)F, 0);
+        for (int f = c.inc_F; f < F; f++) {
+            const int a = gp.h_fa.p[f], b = gp.h_fb.p[f];
+            c.wt[f] = (f < (int)gp.asym.size() && gp.asym[f] && b >= 0 && c.model.pos[b] < c.model.pos[a]) ? 1 : 0;
+            c.wt_any = c.wt_any || c.wt[f];
+        }
+    }
     std::vector<RefModel::Visit> &visits = c.visits;
     const bool partial = c.model.naffected <= 5;     // aprilsam.c:755: otherwise the whole tree is walked
     // structural: which poses the reference's solve_node touches.  A partial walk's list decides what the GPU back-substitutes: now.  A
@@ -510,7 +524,8 @@ static double chi2_impl(april_graph_t *g) {
             const int gi = gp.p2g[idx];
             if (gi == last) continue;                      // (the pairs of a factor with more than two nodes: one evaluation)
             last = gi;
-            april_graph_factor_eval_t *e = fs[gi]->eval(fs[gi], g, nullptr);
+            april_graph_factor_eval_t *e = fs[gi]->eval ? fs[gi]->eval(fs[gi], g, nullptr) : nullptr;
+            if (!e) fail(ERR_BAD_GRAPH, "factor %d: eval() returned no evaluation (aprilsam.h:75-89)", gi);      // (never takes the process down: errors.h)
             chi2 += e->chi2;
             april_graph_factor_eval_destroy(e);
         }

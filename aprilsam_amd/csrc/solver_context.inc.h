@@ -12,12 +12,8 @@ struct LevelPlan {
     long long full_limit = 0;                                  // ... fully in LDS when their array fits this many bytes, else panel mode
     int small_nt = 512;                                        // ... with this many threads per workgroup
     int n_big = 0; size_t asm_lds = 0;
-    Launch asm_big{}, asm_tile{};                              // k_assemble_big (chunks of block columns) / k_assemble_tile (windows, option tile_assembly)
-    std::vector<Launch> syrka, syrkb;                          // look-ahead split of the wide update (modes 2, 3), same indexing as syrkw
-    std::vector<Launch> panel, syrk, syrkw;                    // per panel step: diag+panel, narrow update, wide update (grid 0 unless the step closes an outer block)
-    std::vector<Launch> bchain, btile;                         // per outer block (option block_panels): diagonal-block workgroups, row tiles (Launch::tile = rows per wave / 16)
-    std::vector<int> diag_slot0;                               // per panel step: first slot of its factored diagonal blocks in d_diag (multi-tile steps)
-    int wb_off = 0, n_wb = 0, n_diag_slots = 0;                // k_diag_writeback entries (3 ints each) of the level, slots used
+    Launch asm_big{};                                          // k_assemble_big (chunks of block columns)
+    std::vector<Launch> bchain, btile, syrkw;                  // per 128-column outer block: diagonal-block workgroups, row tiles (Launch::tile = rows per wave / 16), the wide update that closes it (Launch::tile = output tile)
     int all_off = 0, n_all = 0; size_t solve_lds = 0;          // every front (k_backsolve)
     size_t solve_w_lds = 0; int maxns = 0;                     // ... in the column-per-lane form (k_backsolve_w: L panel in LDS), widest own part
     Launch bs_gemv{};                                          // fronts whose update-row product is spread over workgroups first (k_backsolve_gemv)
@@ -106,12 +102,14 @@ struct Context {
     RefModel model;                       // the reference's tree / counters (refmodel.cpp), rebuilt lazily after a batch
     PatchList patches;                    // per-step table updates of the incremental fast path
     int batch_factors = 0;                // #factors at the last batch step
-    // look-ahead: the "rest" part of the wide trailing updates runs on a side stream (enqueue_big_steps)
-    hipStream_t s2 = nullptr; std::vector<hipEvent_t> la_ev; size_t la_next = 0;
-    hipEvent_t la_event() {
-        if (la_next == la_ev.size()) { hipEvent_t e; HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); la_ev.push_back(e); }
-        return la_ev[la_next++];
-    }
+    // Factors with an information matrix that is not symmetric as given (GraphPack::asym): wt[f] = 1 when the reference eliminates endpoint b
+    // before endpoint a, i.e. when the block it accumulates is J_b^T W J_a (aprilsam.c:171,520: upper triangle of ITS order only) and not
+    // J_a^T W J_b -- the two are transposes of each other only for a symmetric W.  Fixed when the factor enters the system: at a batch call
+    // for every factor (the reference re-orders everything), at an incremental call for the new ones (old poses keep their positions, new
+    // ones are appended, aprilsam.c:393-396).  Travels to the device as bit 1 of the per-factor swap byte (k_linearize).
+    std::vector<unsigned char> wt; bool wt_any = false, wt_dirty = false;
+    long long wt_serial = -1, wt_topo = -1, wt_content = -1;
+    std::vector<unsigned char> swap_host;          // host copy of d_swap's base-plan part (the source of an asynchronous copy: must outlive it)
     // captured numeric phase
     // multi-level ("persistent") launches of the batch path: the top levels of the tree, where a level holds only a handful
     // of fronts, run as ONE launch for the factorisation and ONE for the back substitution, fronts waiting on per-front
@@ -132,26 +130,50 @@ struct Context {
     int api_key_runs = 0;                          // calls seen with this key: the first one runs without a graph (below)
     // captured graphs that are no longer current: hipGraphExecDestroy takes 0.24 ms on this stack, so they are destroyed while the
     // GPU works on a step (reap_retired), not on the way to the next plan
-    std::vector<hipGraphExec_t> retired;
-    void reap_retired() { for (hipGraphExec_t g : retired) (void)hipGraphExecDestroy(g); retired.clear(); }
-    void retire(hipGraphExec_t &g) { if (g) { if (retired.size() >= 8) reap_retired(); retired.push_back(g); g = nullptr; } }      // (bounded: call sequences that never reach a reaping point)
+    // A retired graph may still have launches in flight (resident / sharded loops enqueue steps without a sync in between): it carries an
+    // event recorded on the stream it was last launched on and is destroyed only once that event has completed.
+    struct Retired { hipGraphExec_t g; hipEvent_t done; };
+    std::vector<Retired> retired;
+    hipStream_t graph_stream = nullptr;            // the stream gexec / gexec_api were last launched on (run_numeric)
+    void reap_retired(bool wait = false) {
+        size_t keep = 0;
+        for (Retired &r : retired) {
+            if (r.done) {
+                if (wait) (void)hipEventSynchronize(r.done);
+                else if (hipEventQuery(r.done) != hipSuccess) { retired[keep++] = r; continue; }
+                (void)hipEventDestroy(r.done);
+            }
+            (void)hipGraphExecDestroy(r.g);
+        }
+        retired.resize(keep);
+    }
+    void retire(hipGraphExec_t &g) {
+        if (!g) return;
+        if (retired.size() >= 8) reap_retired();                   // (bounded: call sequences that never reach a reaping point)
+        if (retired.size() >= 32) reap_retired(true);              // (... and whose launches never finish in between)
+        Retired r{ g, nullptr };
+        if (graph_stream && hipEventCreateWithFlags(&r.done, hipEventDisableTiming) == hipSuccess) {
+            if (hipEventRecord(r.done, graph_stream) != hipSuccess) { (void)hipEventDestroy(r.done); r.done = nullptr; }
+        } else r.done = nullptr;
+        retired.push_back(r); g = nullptr;
+    }
     double lambda_val = -1; int lambda_N = -1;     // what d_lambda currently holds (uniform batch value), -1: unknown
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
         d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release();
         h_done.release(); h_kstamp.release(); d_prof.release(); d_upd.release(); d_wbuf.release(); d_flags.release(); d_flevel.release(); d_perm.release(); d_solve_tab.release(); d_dinv.release(); d_bsb_far.release(); d_bsb_flags.release();
-        retire(gexec); retire(gexec_api); reap_retired();
+        retire(gexec); retire(gexec_api); reap_retired(true);
         if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
         have_events = false;
         for (auto &e : k_ev) (void)hipEventDestroy(e);
         k_ev.clear();
-        for (auto &e : la_ev) (void)hipEventDestroy(e);
-        la_ev.clear(); la_next = 0;
-        if (s2) (void)hipStreamDestroy(s2);
-        s2 = nullptr;
     }
 };
 static std::unordered_map<const void *, std::unique_ptr<Context>> g_ctx;
+
+static void forget_stream(hipStream_t s) {
+    for (auto &kv : g_ctx) if (kv.second->graph_stream == s) kv.second->graph_stream = nullptr;
+}
 
 static Context &ctx_for(const april_graph_cholesky_param_t *p) {
     auto it = g_ctx.find(p);
@@ -243,11 +265,8 @@ static double g_incsub[8] = { 0 }; static long long g_incsub_n = 0;      // APRI
 static const bool g_incprof_stamps = [] { const char *e = getenv("APRILSAM_AMD_INC_PROFILE"); return e && *e == '2'; }();      // (see IncProf)
 static int small_threads_for(size_t n_fronts) { return (int)n_fronts >= g_opt.tp_fronts ? std::min(g_opt.small_threads, g_opt.tp_threads) : g_opt.small_threads; }
 
-// doubles of d_diag a level needs: one (NB x NB+1) slot per parked diagonal block (per-panel forms) or four NB x NB inverse
-// blocks per active front (outer-block panels)
-static size_t diag_doubles(int n_big, int n_diag_slots) {
-    return std::max((size_t)(std::max(n_big, n_diag_slots) + 64) * NB * (NB + 1), (size_t)std::max(n_big, 1) * OBP * NB * NB);
-}
+// doubles of d_diag a level needs: four NB x NB inverse blocks per active front (the fronts that keep none of their own, FrontDesc::dinv0)
+static size_t diag_doubles(int n_big) { return (size_t)std::max(n_big, 1) * OBP * NB * NB; }
 // classify the fronts of one level (small / big) and append their launch tables to `tab`
 constexpr int BSB_MAX_WGS = 64;               // chain + helper workgroups of one k_backsolve_blk launch (they must be resident together)
 template <class Dims, class KeepInv>
@@ -306,7 +325,6 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
         return La;
     };
     L.asm_big = make((int)big.size(), [&](int t) { return asm_chunks(cols(t) / 3); });
-    L.asm_tile = make((int)big.size(), [&](int t) { return at_tiles(cols(t) / 3); });
     {   // back substitution of the multi-workgroup fronts 128 columns at a time (k_backsolve_blk): fronts whose inverse
         // diagonal blocks are kept (keep_inv) and whose update-row product comes from k_backsolve_gemv (or is empty);
         // the whole level or nothing: chains + helpers must fit BSB_MAX_WGS workgroups
@@ -319,7 +337,7 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
             if (isbig && 3 * a <= BSB_FAR && (b == 0 || bs_split_front(a, b)) && keep_inv(t)) { wide.push_back(t); wgs += 1 + bsb_helpers(3 * a); }
             else rest.push_back(t);
         }
-        if (!wide.empty() && wgs <= BSB_MAX_WGS && g_opt.block_panels && g_opt.blk_backsolve) {
+        if (!wide.empty() && wgs <= BSB_MAX_WGS && g_opt.blk_backsolve) {
             const int lo = (int)tab.size();
             tab.insert(tab.end(), wide.begin(), wide.end());
             L.bs_blk = Launch{ lo, (int)tab.size(), (int)wide.size(), 0, false };
@@ -332,41 +350,20 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
             L.rest_lds = (mm + NB + 8 + NB * (NB + 1)) * 8;
         }
     }
-    int steps = (3 * nsb_of(big[0]) + NB - 1) / NB;
+    const int steps = (3 * nsb_of(big[0]) + NB - 1) / NB;
     auto active = [&](int sidx) { int nact = 0; while (nact < (int)big.size() && 3 * nsb_of(big[nact]) > sidx * NB) nact++; return nact; };
-    std::vector<int> wb;
-    for (int sidx = 0; sidx < steps; sidx++) {
-        const int nact = active(sidx);
-        L.panel.push_back(make(nact, [&](int t) { return panel_tiles(rows(t), 3 * nsb_of(t), sidx, g_opt.left_panels && g_opt.fused_panel ? PANEL_ROWS_LL : PANEL_ROWS); }));
-        L.diag_slot0.push_back(L.n_diag_slots);
-        if (!L.panel.back().single || (g_opt.left_panels && g_opt.fused_panel)) {   // the factored diagonal blocks wait in d_diag until the level's write-back
-            for (int i = 0; i < nact; i++) { wb.push_back(big[i]); wb.push_back(sidx); wb.push_back(L.n_diag_slots + i); }
-            L.n_diag_slots += nact;
+    // the wide update that closes every outer block of OBP panels (K = the block's columns, everything to its right)
+    for (int o = 0; o * OBP < steps; o++) {
+        const int s_lo = o * OBP, s_hi = std::min(s_lo + OBP, steps), nact = active(s_lo);
+        int tile = TILE;
+        if (g_opt.syrk_small_tiles > 0) {         // few tiles: 32 x 32 ones (k_syrk_big32)
+            long long nt64 = 0;
+            for (int i = 0; i < nact; i++) nt64 += syrk_tiles(rows(big[i]), cols(big[i]), 3 * nsb_of(big[i]), s_lo, s_hi, TILE);
+            if (nt64 < g_opt.syrk_small_tiles) tile = TILE / 2;
         }
-        L.syrk.push_back(make(nact, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), sidx, sidx + 1, 0); }));
-        if ((sidx + 1) % OBP == 0 || sidx + 1 == steps) {
-            const int s_lo = sidx / OBP * OBP;
-            // wide trailing matrices go to the LDS-staged 128 x 128 kernel (decided per launch on the largest front)
-            int span = 0;
-            for (int i = 0; i < active(s_lo); i++) { SyrkRange r = syrk_range(rows(big[i]), cols(big[i]), 3 * nsb_of(big[i]), s_lo, sidx + 1, 1); if (r.ntr > 0) span = std::max(span, rows(big[i]) - 2 - r.col_lo); }
-            int tile = span >= g_opt.syrk128_rows ? TILE2 : TILE;
-            if (tile == TILE && g_opt.syrk_small_tiles > 0) {         // few tiles: 32 x 32 ones (k_syrk_big32)
-                long long nt64 = 0;
-                for (int i = 0; i < active(s_lo); i++) nt64 += syrk_tiles(rows(big[i]), cols(big[i]), 3 * nsb_of(big[i]), s_lo, sidx + 1, 1, TILE);
-                if (nt64 < g_opt.syrk_small_tiles) tile = TILE / 2;
-            }
-            L.syrkw.push_back(make(active(s_lo), [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, sidx + 1, 1, tile); }));
-            L.syrkw.back().tile = tile;
-            L.syrka.push_back(make(active(s_lo), [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, sidx + 1, 2); }));
-            L.syrkb.push_back(make(active(s_lo), [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, sidx + 1, 3, tile); }));
-            L.syrkb.back().tile = tile;
-        } else {
-            L.syrkw.push_back(Launch{ 0, 0, 0, 0, false });
-            L.syrka.push_back(Launch{ 0, 0, 0, 0, false }); L.syrkb.push_back(Launch{ 0, 0, 0, 0, false });
-        }
+        L.syrkw.push_back(make(nact, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, s_hi, tile); }));
+        L.syrkw.back().tile = tile;
     }
-    L.wb_off = (int)tab.size(); L.n_wb = (int)wb.size() / 3;
-    tab.insert(tab.end(), wb.begin(), wb.end());
     // outer-block panels (kernels.hip.h: k_block_chain / k_block_solve): per 128-column outer block the active fronts (a
     // prefix of `big`, sorted by own columns) and their row tiles below the diagonal block
     for (int o = 0; o * OBP < steps; o++) {
@@ -387,6 +384,12 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
 struct ShardLayout { std::vector<long long> off; std::vector<char> ghost; long long pool_doubles = 0; };
 
 // upload the symbolic plan and build the per-level launch tables
+// per-factor swap byte of the base plan: bit 0 = the off-diagonal block is stored transposed (Plan::fac_swap), bit 1 = Context::wt
+static void fill_swap_host(Context &c) {
+    const Plan &P = c.plan;
+    c.swap_host.assign(P.fac_swap.begin(), P.fac_swap.end());
+    if (c.wt_any) for (size_t f = 0; f < c.swap_host.size() && f < c.wt.size(); f++) c.swap_host[f] |= (unsigned char)(c.wt[f] << 1);
+}
 static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = nullptr) {
     const Plan &P = c.plan;
     const bool uprof = getenv("APRILSAM_AMD_PLAN_PROFILE") != nullptr;
@@ -448,7 +451,9 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     d.schur_first_nub = std::max(0, g_opt.schur_first);
     if (getenv("APRILSAM_AMD_KPROF")) { c.d_prof.need((size_t)PROF_SLOTS * P.nF); HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)8 * PROF_SLOTS * P.nF, s)); d.prof = c.d_prof.p; d.prof_mode = atoi(getenv("APRILSAM_AMD_KPROF")) >= 2 ? atoi(getenv("APRILSAM_AMD_KPROF")) : 1; }
     c.d_swap.need((size_t)P.F + INC_FACT_); c.d_pos.need((size_t)P.N + INC_NODES_);
-    HIPCHECK(hipMemcpyAsync(c.d_swap.p, P.fac_swap.data(), P.F, hipMemcpyHostToDevice, s));
+    fill_swap_host(c);
+    HIPCHECK(hipMemcpyAsync(c.d_swap.p, c.swap_host.data(), P.F, hipMemcpyHostToDevice, s));
+    c.wt_dirty = false;
     HIPCHECK(hipMemcpyAsync(c.d_pos.p, P.pos.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
     c.d_perm.need((size_t)P.N + INC_NODES_);
     HIPCHECK(hipMemcpyAsync(c.d_perm.p, P.perm.data(), (size_t)P.N * 4, hipMemcpyHostToDevice, s));
@@ -526,8 +531,8 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     {   // (a param that is used incrementally: fronts near the root collect the rows of every loop closure since the plan was made and
         // may outgrow the single-workgroup kernel -- room for a few of them on the multi-workgroup path, whose scratch a plan without
         // such fronts would not have; measured on the M3500 demo: 13 steps re-planned for 70 KB of scratch)
-        size_t mx = inc ? diag_doubles(16, 512) : 1;
-        for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, diag_doubles(c.levels[l].n_big, c.levels[l].n_diag_slots));
+        size_t mx = inc ? diag_doubles(160) : 1;          // (incremental steps: room for the big fronts of a regenerated level; a step that needs more re-plans, inc_fail(11))
+        for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, diag_doubles(c.levels[l].n_big));
         c.d_diag.need(mx);
     }
     if (uprof) fprintf(stderr, "aprilsam_amd upload: graphs destroyed + descriptors %.3f, index arrays + copies %.3f, launch tables %.3f, last copies + sync %.3f, pools %.3f ms\n", u1 - u0, u2 - u1, u3 - u2, u4 - u3, now_ms() - u4);
@@ -547,7 +552,6 @@ static void set_small_attr() {
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_t<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_block_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_backsolve_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHECK(hipFuncSetAttribute((const void *)k_assemble_tile, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_block_solve<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_block_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_inc_one<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -588,140 +592,48 @@ static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic 
 static void launch_front_persist(Context &c, hipStream_t s) {
     const int *list = c.d_tab.p + c.p_up_off;
     int *fl = c.d_flags.p;
-    if (c.p_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(c.p_up_n), dim3(1024), c.p_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, g_opt.block_factor, fl, 1);
-    else if (c.p_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(c.p_up_n), dim3(512), c.p_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, g_opt.block_factor, fl, 1);
-    else hipLaunchKernelGGL(k_front_small<256>, dim3(c.p_up_n), dim3(256), c.p_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, g_opt.block_factor, fl, 1);
+    if (c.p_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(c.p_up_n), dim3(1024), c.p_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, fl, 1);
+    else if (c.p_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(c.p_up_n), dim3(512), c.p_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, fl, 1);
+    else hipLaunchKernelGGL(k_front_small<256>, dim3(c.p_up_n), dim3(256), c.p_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, fl, 1);
 }
 
 static void launch_front_small(Context &c, const LevelPlan &L, hipStream_t s, const int *tab = nullptr) {
     if (!tab) tab = c.d_tab.p;
     const int nt = L.small_nt;
-    if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor, (int *)nullptr, 0);
-    else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor, (int *)nullptr, 0);
-    else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, g_opt.block_factor, (int *)nullptr, 0);
+    if (nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(L.n_small), dim3(1024), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, (int *)nullptr, 0);
+    else if (nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(L.n_small), dim3(512), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, (int *)nullptr, 0);
+    else hipLaunchKernelGGL(k_front_small<256>, dim3(L.n_small), dim3(256), L.small_lds, s, c.dp, tab + L.small_off, c.d_pool.p, c.d_H.p, c.d_bad.p, L.full_limit, (int *)nullptr, 0);
 }
 
-// panel steps of the big fronts of one level: per NB-column panel {diagonal block, row solves, narrow update};
-// after every OBP panels one wide update with K = OBP * NB (kernels.hip.h: syrk_range)
+// The big fronts of one level, 128 columns (an outer block of OBP panels) at a time: diagonal block in LDS with the inverses of its four
+// 32 x 32 diagonal blocks as a by-product (k_block_chain), row solves on the matrix cores (k_block_solve), then ONE wide update of
+// everything to the right with K = the block's columns (k_syrk_big / k_syrk_big32).
 template <class Tic, class Toc>
-static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, bool la = false, const int *tab = nullptr) {
+static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, const int *tab = nullptr) {
     if (!tab) tab = c.d_tab.p;
-    auto wide = [&](const Launch &w, int k, int mode, hipStream_t st) {
-        if (w.tile == TILE / 2)
-            hipLaunchKernelGGL(k_syrk_big32, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode | (std::max(0, g_opt.syrk_xcd_order) << SYRK_MODE_XCD_SHIFT), c.d_pool.p);
-        else if (w.tile == TILE2)
-            hipLaunchKernelGGL(k_syrk_big128, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode, c.d_pool.p);
-        else if (g_opt.syrk_variant == 1)
-            hipLaunchKernelGGL(k_syrk_big_w2, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode | (std::max(0, g_opt.syrk_xcd_order) << SYRK_MODE_XCD_SHIFT), c.d_pool.p);
-        else
-            hipLaunchKernelGGL(k_syrk_big, dim3(w.grid), dim3(TPB), 0, st, c.dp, tab + w.list_off, tab + w.pre_off, w.n, k / OBP * OBP, k + 1, mode | (std::max(0, g_opt.syrk_xcd_order) << SYRK_MODE_XCD_SHIFT), c.d_pool.p);
-    };
-    if (la && !c.s2) {        // lowest priority: its big kernels must not delay the one-workgroup kernels of the chain
-        int lo = 0, hi = 0;
-        HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHECK(hipStreamCreateWithPriority(&c.s2, hipStreamNonBlocking, lo));
-    }
-    if (g_opt.block_panels) {
-        // outer-block panels: per 128-column outer block {diagonal block in LDS, row solves on the matrix cores, wide update}.
-        // Look-ahead (la): the wide update is split -- "ahead" = the next outer block's columns, on this stream, all the next
-        // diagonal block and row solves need; "rest" = everything right of them, on the side stream beside that chain.  Both
-        // write disjoint columns; the next "ahead" and "rest" touch columns the previous "rest" wrote, so they wait for it.
-        const int steps = (int)L.panel.size();
-        hipEvent_t rest_done = nullptr;
-        for (size_t o = 0; o < L.bchain.size(); o++) {
-            const Launch &bc = L.bchain[o], &bt = L.btile[o];
-            tic(K_PANEL_BIG);
-            hipLaunchKernelGGL(k_block_chain, dim3(bc.n), dim3(BCH_THREADS), block_chain_lds(), s, c.dp, tab + bc.list_off, (int)o, c.d_pool.p, c.d_diag.p, c.d_dinv.p, c.d_bad.p);
-            if (bt.grid > 0) {
-                if (bt.tile == 2) hipLaunchKernelGGL(k_block_solve<2>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p, c.d_dinv.p);
-                else hipLaunchKernelGGL(k_block_solve<1>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p, c.d_dinv.p);
-            }
-            toc();
-            const int k = std::min((int)(o + 1) * OBP, steps) - 1;      // the panel step that closes the outer block carries its wide update
-            if (!la) {
-                const Launch &sw = L.syrkw[k];
-                if (sw.grid > 0) { tic(K_SYRK_BIG); wide(sw, k, 1, s); toc(); }
-                continue;
-            }
-            const Launch &sa = L.syrka[k], &sb = L.syrkb[k];
-            if (sb.grid > 0) {
-                hipEvent_t solved = c.la_event();
-                HIPCHECK(hipEventRecord(solved, s));
-                HIPCHECK(hipStreamWaitEvent(c.s2, solved, 0));
-                wide(sb, k, 3, c.s2);                       // (same stream as the previous "rest": in order behind it)
-            }
-            if (sa.grid > 0) {
-                if (rest_done) HIPCHECK(hipStreamWaitEvent(s, rest_done, 0));
-                wide(sa, k, 2, s);
-            }
-            if (sb.grid > 0) { rest_done = c.la_event(); HIPCHECK(hipEventRecord(rest_done, c.s2)); }
+    const int xcd = std::max(0, g_opt.syrk_xcd_order) << SYRK_MODE_XCD_SHIFT;
+    for (size_t o = 0; o < L.bchain.size(); o++) {
+        const Launch &bc = L.bchain[o], &bt = L.btile[o], &sw = L.syrkw[o];
+        tic(K_PANEL_BIG);
+        hipLaunchKernelGGL(k_block_chain, dim3(bc.n), dim3(BCH_THREADS), block_chain_lds(), s, c.dp, tab + bc.list_off, (int)o, c.d_pool.p, c.d_diag.p, c.d_dinv.p, c.d_bad.p);
+        if (bt.grid > 0) {
+            if (bt.tile == 2) hipLaunchKernelGGL(k_block_solve<2>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p, c.d_dinv.p);
+            else hipLaunchKernelGGL(k_block_solve<1>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p, c.d_dinv.p);
         }
-        if (rest_done) HIPCHECK(hipStreamWaitEvent(s, rest_done, 0));      // join: the next level reads the update blocks
-        return;
-    }
-    hipEvent_t rest_done = nullptr;          // completion of the latest "rest" update on the side stream
-    for (size_t k = 0; k < L.panel.size(); k++) {
-        const Launch &pa = L.panel[k], &sy = L.syrk[k], &sw = L.syrkw[k];
-        const bool ll = g_opt.left_panels && g_opt.fused_panel;       // left-looking panels: no narrow update launches
-        if (ll) {
-            tic(K_PANEL_BIG);
-            hipLaunchKernelGGL(k_diagpanel_ll, dim3(pa.grid), dim3(TPB), 0, s, c.dp, tab + pa.list_off, tab + pa.pre_off, pa.n, (int)k, c.d_pool.p,
-                               c.d_diag.p, L.diag_slot0[k], c.d_bad.p);
-            toc();
-        } else if (pa.single) {          // one row tile per front: diagonal block + row solves in one launch
-            tic(K_PANEL_BIG);
-            hipLaunchKernelGGL(k_diagpanel_big, dim3(pa.n), dim3(TPB), 0, s, c.dp, tab + pa.list_off, (int)k, c.d_pool.p, c.d_bad.p);
-            toc();
-        } else if (g_opt.fused_panel) {   // several row tiles per front: every tile factors the diagonal block itself, one launch
-            tic(K_PANEL_BIG);
-            hipLaunchKernelGGL(k_diagpanel_multi, dim3(pa.grid), dim3(TPB), 0, s, c.dp, tab + pa.list_off, tab + pa.pre_off, pa.n, (int)k, c.d_pool.p,
-                               c.d_diag.p, L.diag_slot0[k], c.d_bad.p);
-            toc();
-        } else {
-            tic(K_DIAG_BIG);
-            hipLaunchKernelGGL(k_diag_big, dim3(pa.n), dim3(64), 0, s, c.dp, tab + pa.list_off, (int)k, c.d_pool.p, c.d_diag.p, c.d_bad.p);
-            toc();
-            tic(K_PANEL_BIG);
-            hipLaunchKernelGGL(k_panel_big, dim3(pa.grid), dim3(TPB), 0, s, c.dp, tab + pa.list_off, tab + pa.pre_off, pa.n, (int)k, c.d_pool.p, c.d_diag.p);
-            toc();
-        }
-        if (sy.grid > 0 && !ll) {
-            tic(K_SYRK_BIG);
-            hipLaunchKernelGGL(k_syrk_big_w2, dim3(sy.grid), dim3(TPB), 0, s, c.dp, tab + sy.list_off, tab + sy.pre_off, sy.n, (int)k, (int)k + 1, 0, c.d_pool.p);
-            toc();
-        }
-        if (!la) {
-            if (sw.grid > 0) { tic(K_SYRK_BIG); wide(sw, (int)k, 1, s); toc(); }
-            continue;
-        }
-        // Look-ahead.  "ahead" = the next outer block's panel columns: stays on this stream, the chain of small kernels
-        // that follows needs it.  "rest" = everything right of them: side stream, overlapped with that chain.  Both read
-        // this outer block's columns and write disjoint column ranges.  The previous "rest" wrote the columns "ahead"
-        // updates now (and the ones this "rest" updates: same stream, in order), so "ahead" waits for it.
-        const Launch &sa = L.syrka[k], &sb = L.syrkb[k];
-        if (sb.grid > 0) {
-            hipEvent_t chain_done = c.la_event();
-            HIPCHECK(hipEventRecord(chain_done, s));
-            HIPCHECK(hipStreamWaitEvent(c.s2, chain_done, 0));
-            wide(sb, (int)k, 3, c.s2);
-        }
-        if (sa.grid > 0) {
-            if (rest_done) HIPCHECK(hipStreamWaitEvent(s, rest_done, 0));
-            wide(sa, (int)k, 2, s);
-        }
-        if (sb.grid > 0) { rest_done = c.la_event(); HIPCHECK(hipEventRecord(rest_done, c.s2)); }
-    }
-    if (rest_done) HIPCHECK(hipStreamWaitEvent(s, rest_done, 0));      // join: the next level reads the update blocks
-    if (g_opt.fused_panel && L.n_wb > 0) {       // the diagonal blocks parked by k_diagpanel_multi go into their fronts
-        tic(K_DIAG_BIG);
-        hipLaunchKernelGGL(k_diag_writeback, dim3(L.n_wb), dim3(TPB), 0, s, c.dp, tab + L.wb_off, c.d_pool.p, c.d_diag.p);
         toc();
+        if (sw.grid > 0) {
+            tic(K_SYRK_BIG);
+            // (s_lo, s_hi) in panel steps: the kernel clips s_hi * NB to the front's own columns
+            if (sw.tile == TILE / 2) hipLaunchKernelGGL(k_syrk_big32, dim3(sw.grid), dim3(TPB), 0, s, c.dp, tab + sw.list_off, tab + sw.pre_off, sw.n, (int)o * OBP, (int)(o + 1) * OBP, 1 | xcd, c.d_pool.p);
+            else hipLaunchKernelGGL(k_syrk_big, dim3(sw.grid), dim3(TPB), 0, s, c.dp, tab + sw.list_off, tab + sw.pre_off, sw.n, (int)o * OBP, (int)(o + 1) * OBP, 1 | xcd, c.d_pool.p);
+            toc();
+        }
     }
 }
 
 // kernels of one level of the factorisation (small LDS fronts, big multi-workgroup path)
 template <class Tic, class Toc>
-static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, bool la = false, const int *tab = nullptr) {
+static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, Tic tic, Toc toc, const int *tab = nullptr) {
     if (!tab) tab = c.d_tab.p;
     if (L.n_small) {
         tic(K_FRONT_SMALL);
@@ -730,14 +642,10 @@ static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, 
     }
     if (L.n_big) {
         tic(K_ASSEMBLE_BIG);
-        if (g_opt.tile_assembly)
-            hipLaunchKernelGGL(k_assemble_tile, dim3(L.asm_tile.grid), dim3(TPB), at_lds(), s, c.dp, tab + L.asm_tile.list_off,
-                               tab + L.asm_tile.pre_off, L.asm_tile.n, c.d_pool.p, c.d_H.p);
-        else
-            hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, tab + L.asm_big.list_off,
-                               tab + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
+        hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, tab + L.asm_big.list_off,
+                           tab + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
         toc();
-        enqueue_big_steps(c, L, s, tic, toc, la, tab);
+        enqueue_big_steps(c, L, s, tic, toc, tab);
     }
 }
 
@@ -777,9 +685,8 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     }
     toc();
     if (ev) HIPCHECK(hipEventRecord(ev[1], s));
-    c.la_next = 0;
     const int l0 = c.persist_l0 >= 0 ? c.persist_l0 : P.nLevels;        // levels >= l0: one multi-level launch each way
-    for (int l = 0; l < l0; l++) { cur_level = l; enqueue_factor_level(c, c.levels[l], s, tic, toc, !ktime && g_opt.lookahead); }
+    for (int l = 0; l < l0; l++) { cur_level = l; enqueue_factor_level(c, c.levels[l], s, tic, toc); }
     cur_level = l0;
     if (l0 < P.nLevels) { tic(K_FRONT_SMALL); launch_front_persist(c, s); toc(); }
     if (ev) HIPCHECK(hipEventRecord(ev[2], s));
@@ -838,6 +745,7 @@ static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp
                 HIPCHECK(hipGraphInstantiate(&c.gexec_api, graph, nullptr, nullptr, 0));
                 HIPCHECK(hipGraphDestroy(graph));
             }
+            c.graph_stream = s;
             HIPCHECK(hipGraphLaunch(c.gexec_api, s));
         } else {
             enqueue_numeric(c, gp, s, timing ? c.ev : nullptr, false, false, true);
@@ -855,6 +763,7 @@ static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp
             HIPCHECK(hipGraphDestroy(graph));
             c.gexec_key = (const void *)gp.d_state.p; c.gexec_serial = gp.serial;
         }
+        c.graph_stream = s;
         HIPCHECK(hipGraphLaunch(c.gexec, s));
     } else {
         enqueue_numeric(c, gp, s, timing ? c.ev : nullptr, unary_at_lp);
@@ -876,6 +785,35 @@ static double device_chi2(GraphPack &gp) {     // chi^2 at d_state; synchronises
 // that touches either (api_set_option bumps g_opt_epoch) therefore forces a re-plan and a re-capture on every param.
 static long long g_opt_epoch = 0;
 static long long launch_table_key() { return g_opt_epoch; }
+// Batch-like calls, BEFORE prepare_plan: (re)derive Context::wt from the reference's own elimination order of the packed graph
+// (refmodel.cpp restates it, aprilsam.c:999-1249) when the graph holds factors with an asymmetric W.  Graphs without such factors -- every
+// graph the reference ships or generates -- pay one integer comparison.  Returns true when it ran the model (c.model then describes this
+// batch step: the caller need not compute it again).
+static bool orient_asymmetric(Context &c, GraphPack &gp) {
+    if (gp.n_asym == 0) {
+        if (c.wt_any) { c.wt.clear(); c.wt_any = false; c.wt_dirty = true; c.wt_serial = -1; }
+        return false;
+    }
+    if (!gp.host_idx.empty()) fail(ERR_UNSUPPORTED, "factors with an asymmetric information matrix next to factors of foreign types: the reference's result depends on its elimination "
+                                                    "order here (aprilsam.c:171), which this library only models for xyt / xytpos graphs");
+    if (c.wt_serial == gp.serial && c.wt_topo == gp.topo_version && c.wt_content == gp.content_version && (int)c.wt.size() == gp.F) return false;
+    const int N = gp.N, F = gp.F;
+    c.model.batch(N, F, gp.h_fa.p, gp.h_fb.p);
+    c.wt.assign((size_t)F, 0); c.wt_any = false;
+    for (int f = 0; f < F; f++) {
+        const int a = gp.h_fa.p[f], b = gp.h_fb.p[f];
+        if (gp.asym[f] && b >= 0 && c.model.pos[b] < c.model.pos[a]) { c.wt[f] = 1; c.wt_any = true; }
+    }
+    c.wt_serial = gp.serial; c.wt_topo = gp.topo_version; c.wt_content = gp.content_version; c.wt_dirty = true;
+    return true;
+}
+// ... and AFTER it: the swap bytes of a REUSED plan follow a changed orientation (a fresh upload carries them already)
+static void flush_orientation(Context &c, hipStream_t s) {
+    if (!c.wt_dirty || !c.have_plan || !c.d_swap.p) return;
+    fill_swap_host(c);
+    HIPCHECK(hipMemcpyAsync(c.d_swap.p, c.swap_host.data(), c.swap_host.size(), hipMemcpyHostToDevice, s));
+    c.wt_dirty = false;
+}
 // make sure plan / device buffers match the packed graph; returns true if the plan was reused
 static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g, bool upload = true) {
     const int N = gp.N, F = gp.F;

@@ -126,7 +126,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
                 I.xfac[T].push_back(f);
                 for (int k = 0; k < 3; k++) new_slot_blk[(size_t)3 * (f - Fold) + k] = c.inc_slot_blk[(size_t)3 * (f - I.Fb) + k] = I.slots_used++;
                 for (int k = 0; k < 2; k++) new_slot_rhs[(size_t)2 * (f - Fold) + k] = c.inc_slot_rhs[(size_t)2 * (f - I.Fb) + k] = I.slots_used++;
-                new_swap[f - Fold] = fb[f] >= 0 && fa[f] < fb[f];
+                new_swap[f - Fold] = (unsigned char)((fb[f] >= 0 && fa[f] < fb[f] ? 1 : 0) | ((c.wt_any && f < (int)c.wt.size() && c.wt[f]) ? 2 : 0));
             }
             FrontDesc &D = I.fd[T];
             D.nsb = n_new; D.nub = nph; I.cur_nub[T] = nph;
@@ -182,9 +182,9 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             const IncFlags nofl{ nullptr, 0, nullptr, 0, nullptr, 0 };
             const int *dn = c.d_tab.p + I.tab_used; const int n_dn = solve_here ? 0 : (int)lst.size();
             const int one_nt = g_opt.inc_one_threads >= 1024 ? 1024 : g_opt.inc_one_threads >= 512 ? 512 : 256;
-            if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, g_opt.block_factor, c.d_x.p, upd1);
-            else if (one_nt >= 512) hipLaunchKernelGGL(k_inc_one<512>, dim3(1), dim3(512), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, g_opt.block_factor, c.d_x.p, upd1);
-            else hipLaunchKernelGGL(k_inc_one<256>, dim3(1), dim3(256), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, g_opt.block_factor, c.d_x.p, upd1);
+            if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, c.d_x.p, upd1);
+            else if (one_nt >= 512) hipLaunchKernelGGL(k_inc_one<512>, dim3(1), dim3(512), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, c.d_x.p, upd1);
+            else hipLaunchKernelGGL(k_inc_one<256>, dim3(1), dim3(256), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, c.d_x.p, upd1);
             gp.mirror_sync = true;
             gp.new_states = gp.h_out.p;
             HIPCHECK(hipGetLastError());
@@ -372,7 +372,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         FrontDesc &D = I.fd[t];
         if (tail_fast && t == tstep.t) {               // only the descriptor changes: records, children and array stay
             D.nsb = nsb; D.nub = nub; I.cur_nub[t] = nub;
-            for (int f = Fold; f < F; f++) new_swap[f - Fold] = fb[f] >= 0 && fa[f] < fb[f];      // (own poses: local order = id order; see add_factor below)
+            for (int f = Fold; f < F; f++) new_swap[f - Fold] = (unsigned char)((fb[f] >= 0 && fa[f] < fb[f] ? 1 : 0) | ((c.wt_any && f < (int)c.wt.size() && c.wt[f]) ? 2 : 0));      // (own poses: local order = id order; see add_factor below)
             fd_dirty.push_back(t);
             I.recs_stale = t;
             continue;
@@ -416,7 +416,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             for (int f : I.xfac[t]) {
                 if (f < Fold) continue;
                 const int la = local(fa[f]), lb = fb[f] >= 0 ? local(fb[f]) : -1;
-                new_swap[f - Fold] = (lb >= 0 && la < lb);         // (orientation of the off-diagonal block in its contribution slot, for later re-assemblies)
+                new_swap[f - Fold] = (unsigned char)((lb >= 0 && la < lb ? 1 : 0) | ((c.wt_any && f < (int)c.wt.size() && c.wt[f]) ? 2 : 0));         // (orientation of the off-diagonal block in its contribution slot, for later re-assemblies)
                 u.own_f[u.n_own] = f; u.own_la[u.n_own] = la; u.own_lb[u.n_own] = lb; u.own_slot[u.n_own] = fslot[f - Fold]; u.n_own++;
             }
             const int *kb, *ke; kids_of(t, &kb, &ke);
@@ -444,7 +444,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             auto add_factor = [&](int f) {
                 const int a = fa[f], b = fb[f];
                 const int la = local(a), lb = b >= 0 ? local(b) : -1;
-                if (f >= Fold) new_swap[f - Fold] = (lb >= 0 && la < lb);       // orientation of the off-diagonal block
+                if (f >= Fold) new_swap[f - Fold] = (unsigned char)((lb >= 0 && la < lb ? 1 : 0) | ((c.wt_any && f < (int)c.wt.size() && c.wt[f]) ? 2 : 0));       // orientation of the off-diagonal block
                 const int *sb = f < I.Fb ? &P.slot_blk[(size_t)3 * f] : &c.inc_slot_blk[(size_t)3 * (f - I.Fb)];
                 const int *sr = f < I.Fb ? &P.slot_rhs[(size_t)2 * f] : &c.inc_slot_rhs[(size_t)2 * (f - I.Fb)];
                 ents.push_back({ la, la, f, 0, sb[0] }); ents.push_back({ la, -1, f, 3, sr[0] });
@@ -535,22 +535,18 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         if (lev_dirty[l].empty()) continue;
         LevelPlan &L = dl[l];
         const int sh = (int)I.tab_used;
-        L.all_off += sh; L.small_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh; L.asm_tile.list_off += sh; L.asm_tile.pre_off += sh;
-        for (auto &x : L.panel) { x.list_off += sh; x.pre_off += sh; }
-        for (auto &x : L.syrk) { x.list_off += sh; x.pre_off += sh; }
+        L.all_off += sh; L.small_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
-        for (auto &x : L.syrka) { x.list_off += sh; x.pre_off += sh; }
-        for (auto &x : L.syrkb) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.bchain) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.btile) { x.list_off += sh; x.pre_off += sh; }
         L.bs_blk.list_off += sh; L.bs_blk.pre_off += sh; L.rest_off += sh;
-        L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh; L.wb_off += sh;
+        L.bs_gemv.list_off += sh; L.bs_gemv.pre_off += sh;
         if (l < I.nLev0) for (int t : lev_dirty[l]) {
             I.base_levels[l].solve_lds = std::max(I.base_levels[l].solve_lds, (size_t)(3 * (P.f_nsb[t] + I.cur_nub[t]) + NB + 8 + NB * (NB + 1)) * 8);
             I.base_levels[l].solve_w_lds = std::max(I.base_levels[l].solve_w_lds, backsolve_lds(3 * (P.f_nsb[t] + I.cur_nub[t]), 3 * P.f_nsb[t], true));
         }
     }
-    for (int l = 0; l < nLev; l++) if (diag_doubles(dl[l].n_big, dl[l].n_diag_slots) > c.d_diag.cap) return inc_fail(11);
+    for (int l = 0; l < nLev; l++) if (diag_doubles(dl[l].n_big) > c.d_diag.cap) return inc_fail(11);
     // batch on the extended plan: levels >= 1 as ONE multi-level launch per sweep (see enqueue_numeric), when they hold small
     // fronts only
     int mp_up_off = 0, mp_dn_off = 0, mp_n = 0, mp_nt = 0; size_t mp_up_lds = 0, mp_dn_lds = 0; long long mp_full = 0; int mp_dn_maxns = 0;
@@ -740,7 +736,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         const IncFlags fl = (!one && (iu || id)) ? IncFlags{ c.d_flags.p, nFr, c.d_tab.p + iu_off, iu ? iu_n : 0, c.d_tab.p + id_off, id ? id_n : 0 } : IncFlags{ nullptr, 0, nullptr, 0, nullptr, 0 };
         if (tail_fast && !one) {                       // the refactorisation in the prologue's launch, the back substitution in launches of its own
             hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), tail_refactor_lds(), s, pro, fl, c.inl, c.dp, tstep, (const int *)nullptr, 0, (const int *)nullptr, 0,
-                               c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, UpdArgs{});
+                               c.d_pool.p, iu_full, c.d_x.p, UpdArgs{});
         } else if (one) {
             if (g_incprof_stamps) { c.h_kstamp.need(8 + PROF_SLOTS); memset(c.h_kstamp.p, 0, 8 * (8 + PROF_SLOTS)); pro.stamps = c.h_kstamp.p; }
             if (g_opt.inc_one_spin) {                  // completion through a word in pinned memory: the host spins instead of sleeping in hipStreamSynchronize
@@ -750,37 +746,33 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             }
             gp.h_out.need((size_t)3 * N);
             const UpdArgs upd1{ c.d_perm.p, gp.d_lp.p, nullptr, gp.d_dx.p, gp.h_out.p, gp.h_dx.p, c.h_bad.p };
-            if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1, uctx);
-            else if (one_nt >= 512) hipLaunchKernelGGL(k_inc_one<512>, dim3(1), dim3(512), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1, uctx);
-            else hipLaunchKernelGGL(k_inc_one<256>, dim3(1), dim3(256), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, g_opt.block_factor, c.d_x.p, upd1, uctx);
+            if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, c.d_x.p, upd1, uctx);
+            else if (one_nt >= 512) hipLaunchKernelGGL(k_inc_one<512>, dim3(1), dim3(512), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, c.d_x.p, upd1, uctx);
+            else hipLaunchKernelGGL(k_inc_one<256>, dim3(1), dim3(256), one_lds, s, pro, fl, c.inl, c.dp, tstep, c.d_tab.p + iu_off, iu_n, c.d_tab.p + id_off, id_n, c.d_pool.p, iu_full, c.d_x.p, upd1, uctx);
         } else
             hipLaunchKernelGGL(k_inc_prologue, dim3(1), dim3(1024), 0, s, pro, fl, c.inl);
     }
     if (iu && !one) {
         const int *list = c.d_tab.p + iu_off;
-        if (iu_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(iu_n), dim3(1024), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1, uctx);
-        else if (iu_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(iu_n), dim3(512), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1, uctx);
-        else hipLaunchKernelGGL(k_front_small<256>, dim3(iu_n), dim3(256), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, g_opt.block_factor, c.d_flags.p, 1, uctx);
+        if (iu_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(iu_n), dim3(1024), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, c.d_flags.p, 1, uctx);
+        else if (iu_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(iu_n), dim3(512), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, c.d_flags.p, 1, uctx);
+        else hipLaunchKernelGGL(k_front_small<256>, dim3(iu_n), dim3(256), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, c.d_flags.p, 1, uctx);
     }
     for (int l = 0; l < nLev; l++) {
         if (lev_dirty[l].empty() || iu || one) continue;
         if (mp && l >= 1) {
             if (l > 1) continue;
             const int *list = c.d_tab.p + mp_up_off;
-            if (mp_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(mp_n), dim3(1024), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, g_opt.block_factor, c.d_flags.p, 1);
-            else if (mp_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(mp_n), dim3(512), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, g_opt.block_factor, c.d_flags.p, 1);
-            else hipLaunchKernelGGL(k_front_small<256>, dim3(mp_n), dim3(256), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, g_opt.block_factor, c.d_flags.p, 1);
+            if (mp_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(mp_n), dim3(1024), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, c.d_flags.p, 1);
+            else if (mp_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(mp_n), dim3(512), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, c.d_flags.p, 1);
+            else hipLaunchKernelGGL(k_front_small<256>, dim3(mp_n), dim3(256), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, c.d_flags.p, 1);
             continue;
         }
         const LevelPlan &L = dl[l];
         if (L.n_small) launch_front_small(c, L, s);
         if (L.n_big) {
-            if (g_opt.tile_assembly)
-                hipLaunchKernelGGL(k_assemble_tile, dim3(L.asm_tile.grid), dim3(TPB), at_lds(), s, c.dp, c.d_tab.p + L.asm_tile.list_off,
-                                   c.d_tab.p + L.asm_tile.pre_off, L.asm_tile.n, c.d_pool.p, c.d_H.p);
-            else
-                hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
-                                   c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
+            hipLaunchKernelGGL(k_assemble_big, dim3(L.asm_big.grid), dim3(TPB), L.asm_lds, s, c.dp, c.d_tab.p + L.asm_big.list_off,
+                               c.d_tab.p + L.asm_big.pre_off, L.asm_big.n, c.d_pool.p, c.d_H.p);
             enqueue_big_steps(c, L, s, [](int) {}, []() {});
         }
     }

@@ -4,6 +4,7 @@
 // packed graph (SoA, host pinned + device) — one per april_graph_t pointer
 // ------------------------------------------------------------------------------------------------------
 static long long g_pack_serial = 0;
+static void forget_stream(hipStream_t s);      // solver_context.inc.h: no context may record an event on a stream that is about to be destroyed
 struct GraphPack {
     const long long serial = ++g_pack_serial;      // captured hipGraphs are keyed by it: a pack freed and another allocated at the same addresses must not match
     int N = 0, F = 0;                  // packed counts (F: packed factor entries, see pack_factors)
@@ -20,6 +21,16 @@ struct GraphPack {
     int dirty_lo = 0, dirty_hi = 0;    // packed factors whose z / W changed since the last upload
     long long content_version = 0;     // bumped whenever z / W of a packed factor changed
     long long topo_version = 0;        // bumped whenever the packed endpoints (h_fa / h_fb, F) changed in any way: a pattern compared equal at (serial, topo_version) still is
+    // factors whose information matrix is NOT symmetric as given (the reference's text loader fills W[1], W[2], W[5] and leaves W[3], W[6],
+    // W[7] zero, examples/aprilsam_demo.c:73-75): the reference accumulates only blocks in the upper triangle of ITS elimination order with
+    // W as given (aprilsam.c:171,520), so the off-diagonal block of such a factor depends on which endpoint it eliminates first
+    // (solver_context.inc.h: orient_asymmetric)
+    std::vector<unsigned char> asym; int n_asym = 0;
+    void note_asym(int p, const double *w, bool device_factor) {
+        const unsigned char a = device_factor && (w[1] != w[3] || w[2] != w[6] || w[5] != w[7]);
+        if ((size_t)p >= asym.size()) asym.resize((size_t)p + 1, 0);
+        n_asym += (int)a - (int)asym[p]; asym[p] = a;
+    }
     std::vector<char> is_host;         // per factor: evaluated on the host through factor->eval
     std::vector<double> h_upt; DBuf<double> d_upt;   // unary factors: the state they were linearised at when they entered the system (3 per factor)
     int F_cap = 0;                     // device capacity (factors) of d_fa/d_fb/d_z/d_W/d_chi2f
@@ -37,7 +48,7 @@ struct GraphPack {
         h_fa.release(); h_fb.release(); h_z.release(); h_W.release(); h_state.release(); h_lp.release(); h_dx.release();
         d_fa.release(); d_fb.release(); d_z.release(); d_W.release(); d_state.release(); d_lp.release(); d_dx.release();
         d_chi2f.release(); d_scalar.release(); h_scalar.release(); h_hostH.release(); d_hostH.release(); d_host_idx.release(); d_upt.release();
-        if (stream) (void)hipStreamDestroy(stream);
+        if (stream) { forget_stream(stream); (void)hipStreamDestroy(stream); }
         stream = nullptr;
     }
 };
@@ -85,7 +96,7 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_ol
     // (incremental calls only ever look at the factors added since the previous call, aprilsam.c:508-511: first and last packed pointer
     // as a sanity check instead of all of them -- the comparison of 5 000 pointers was a microsecond of every step)
     if (valid && trust) valid = from == 0 || (validate_old ? memcmp(gp.fptr.data(), fs, sizeof(void *) * from) == 0 : (gp.fptr[0] == fs[0] && gp.fptr[from - 1] == fs[from - 1]));
-    auto restart = [&]() { gp.topo_version++; from = 0; gp.F = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; gp.is_host.clear(); gp.p2g.clear(); gp.vslot.clear(); gp.g2p.assign(1, 0); };
+    auto restart = [&]() { gp.topo_version++; from = 0; gp.F = 0; gp.F_on_device = 0; gp.host_idx.clear(); gp.host_evaluated = 0; gp.is_host.clear(); gp.p2g.clear(); gp.vslot.clear(); gp.g2p.assign(1, 0); gp.asym.clear(); gp.n_asym = 0; };
     if (!valid) restart();
     // one graph factor -> its packed entries (a, b, host flag, node slots of a host pair, what the pair carries)
     struct Ent { int a, b; bool host; unsigned short slots; unsigned char carry; };
@@ -108,7 +119,10 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_ol
                                   "eval() function pointer (aprilsam.h:110-122)", i, f->type, f->nnodes);
         }
         for (int e = 0; e < ne; e++) {
-            if (ents[e].a < 0 || ents[e].a >= N || ents[e].b >= N) fail(ERR_BAD_GRAPH, "factor %d references node %d / %d of %d", i, ents[e].a, ents[e].b, N);
+            // -1 in `b` is the internal marker of a unary entry: a graph factor with two or more nodes must name real nodes on both sides
+            // (a negative second endpoint used to pass as "unary" with its node slots still naming the missing node)
+            if (ents[e].a < 0 || ents[e].a >= N || ents[e].b >= N || (f->nnodes >= 2 && ents[e].b < 0))
+                fail(ERR_BAD_GRAPH, "factor %d references node %d / %d of %d", i, ents[e].a, ents[e].b, N);
             if (ents[e].a == ents[e].b) fail(ERR_BAD_GRAPH, "factor %d connects node %d to itself", i, ents[e].a);
         }
     };
@@ -130,6 +144,7 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_ol
             double *zp = gp.h_z.p + (size_t)3 * p0, *Wp = gp.h_W.p + (size_t)9 * p0;
             if (memcmp(zp, f->u.common.z, 24) != 0 || memcmp(Wp, f->u.common.W->data, 72) != 0) {
                 memcpy(zp, f->u.common.z, 24); memcpy(Wp, f->u.common.W->data, 72);
+                gp.note_asym(p0, Wp, true);
                 lo = std::min(lo, p0); hi = std::max(hi, p0 + 1);
             }
         }
@@ -144,7 +159,12 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_ol
     int F = gp.g2p[from];
     {   // the pinned mirrors are sized ONCE for everything this call appends (a pinned reallocation costs a quarter of a millisecond)
         size_t total = (size_t)F;
-        for (int i = from; i < Fg; i++) { const int k = fs[i]->nnodes; total += k >= 3 ? (size_t)k * (k - 1) / 2 : 1; }
+        for (int i = from; i < Fg; i++) {
+            // arity is checked BEFORE anything is sized from it: a foreign factor with a garbage nnodes must end in ERR_UNSUPPORTED
+            // (classify() below says so), not in a pinned allocation of k (k - 1) / 2 entries
+            const int k = fs[i]->nnodes;
+            total += (k >= 3 && k <= 11) ? (size_t)k * (k - 1) / 2 : 1;
+        }
         gp.h_fa.need(total, true); gp.h_fb.need(total, true); gp.h_z.need(3 * total, true); gp.h_W.need(9 * total, true);
         gp.is_host.resize(total, 0); gp.p2g.resize(total); gp.vslot.resize(total);
     }
@@ -158,10 +178,12 @@ static void pack_factors(GraphPack &gp, const april_graph_t *g, bool validate_ol
             gp.vslot[F] = (unsigned)ents[e].slots | ((unsigned)ents[e].carry << 16);
             if (ents[e].host) {          // the device kernels see a null factor (W = 0) in its place; k_scatter_host fills its slots
                 memset(gp.h_z.p + (size_t)3 * F, 0, 24); memset(gp.h_W.p + (size_t)9 * F, 0, 72);
+                gp.note_asym(F, gp.h_W.p + (size_t)9 * F, false);
                 gp.host_idx.push_back(F);
             } else {
                 memcpy(gp.h_z.p + (size_t)3 * F, f->u.common.z, 24);
                 memcpy(gp.h_W.p + (size_t)9 * F, f->u.common.W->data, 72);
+                gp.note_asym(F, gp.h_W.p + (size_t)9 * F, true);
             }
         }
         gp.g2p[i + 1] = F;
@@ -200,14 +222,16 @@ static double eval_host_factors(GraphPack &gp, april_graph_t *g, int from) {
     gp.h_hostH.need((size_t)33 * std::max(nh, 1), true);
     april_graph_factor_t **fs = (april_graph_factor_t **)g->factors->data;
     double chi2 = 0;
-    april_graph_factor_eval_t *e = nullptr; int e_of = -1;         // (the pairs of a factor with more than two nodes share one evaluation)
+    // (the pairs of a factor with more than two nodes share one evaluation; the guard destroys the live one on every exit, the fail() paths included)
+    struct EvalGuard { april_graph_factor_eval_t *e = nullptr; ~EvalGuard() { if (e) april_graph_factor_eval_destroy(e); } } guard;
+    april_graph_factor_eval_t *&e = guard.e; int e_of = -1;
     std::vector<double> JtW;
     for (int k = from; k < nh; k++) {
         const int hp = gp.host_idx[k], gi = gp.p2g[hp];
         april_graph_factor_t *f = fs[gi];
         const int x = (int)((gp.vslot[hp] >> 8) & 0xff), y = (int)(gp.vslot[hp] & 0xff), carry = (int)(gp.vslot[hp] >> 16);
         if (gi != e_of) {
-            if (e) april_graph_factor_eval_destroy(e);
+            if (e) { april_graph_factor_eval_destroy(e); e = nullptr; }
             e = f->eval(f, g, nullptr); e_of = gi;
             if (!e || !e->jacobians || !e->jacobians[0] || !e->W || !e->r) fail(ERR_BAD_GRAPH, "factor->eval returned an incomplete evaluation (aprilsam.h:75-89)");
             chi2 += e->chi2;
@@ -242,7 +266,6 @@ static double eval_host_factors(GraphPack &gp, april_graph_t *g, int from) {
             }
         }
     }
-    if (e) april_graph_factor_eval_destroy(e);
     gp.host_evaluated = nh;
     return chi2;
 }

@@ -14,7 +14,9 @@ static int resident_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *p
     pack_factors(gp, g);
     if (!gp.host_idx.empty()) return -4;          // host-evaluated factors need the host in the loop: use april_graph_cholesky
     pack_states(gp, g, false);
+    orient_asymmetric(c, gp);
     const bool reused = prepare_plan(c, gp, g);
+    flush_orientation(c, gp.stream);
     upload_factors(gp);
     set_lambda(c, gp, param->tikhanov);
     if (!c.have_events) { for (auto &e : c.ev) HIPCHECK(hipEventCreate(&e)); c.have_events = true; }
@@ -169,9 +171,8 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
         else {
             // multi-workgroup path.  k_syrk_big gets exactly what its launches are asked for: per outer block of OBP panels the
             // K = block-width update of the lower trapezoid to the right of the block, 2 K flops per element (the kernel also
-            // multiplies the upper halves of its diagonal tiles: executed, not algorithmic, not counted); with right-looking
-            // panels (left_panels = 0) also the narrow updates inside the block.  The panel kernel (k_diagpanel_ll) gets the
-            // rest of the front's sum c_j^2: diagonal blocks, row solves, the left-looking K <= 96 products.
+            // multiplies the upper halves of its diagonal tiles: executed, not algorithmic, not counted).  The panel kernels
+            // (k_block_chain + k_block_solve) get the rest of the front's sum c_j^2: diagonal blocks, row solves, in-block products.
             const double Rv = R - 2;
             double fsy = 0;
             auto trapezoid = [&](double c_lo, double c_hi) { const double n = c_hi - c_lo; return n <= 0 ? 0.0 : n * Rv - (c_lo + c_hi - 1) * n / 2; };   // elements (i >= j) of columns [c_lo, c_hi), rows < Rv
@@ -179,8 +180,6 @@ int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long l
             for (int o = 0; o * OBP < steps; o++) {
                 const double k_lo = (double)o * OBP * NB, k_hi = std::min<double>(ns, (double)(o + 1) * OBP * NB);
                 fsy += 2.0 * (k_hi - k_lo) * trapezoid(k_hi, C);
-                if (!g_opt.block_panels && !(g_opt.left_panels && g_opt.fused_panel))
-                    for (double k1 = k_lo + NB; k1 < k_hi; k1 += NB) fsy += 2.0 * NB * trapezoid(k1, k_hi);
             }
             fsy = std::min(fsy, fl);
             flops[K_SYRK_BIG] += fsy; flops[K_PANEL_BIG] += fl - fsy;
@@ -218,7 +217,9 @@ static int debug_stage_impl(april_graph_t *g, april_graph_cholesky_param_t *para
     pack_factors(gp, g);
     if (!gp.host_idx.empty()) return -4;
     pack_states(gp, g, false);
+    orient_asymmetric(c, gp);
     prepare_plan(c, gp, g);
+    flush_orientation(c, gp.stream);
     upload_factors(gp);
     const Plan &P = c.plan;
     const int N = gp.N, F = gp.F;
@@ -238,7 +239,7 @@ static int debug_stage_impl(april_graph_t *g, april_graph_cholesky_param_t *para
             memcpy(o + 27, &H[(size_t)9 * P.slot_rhs[2 * f]], 24);
             if (gp.h_fb.p[f] < 0) continue;
             const double *b1 = &H[(size_t)9 * P.slot_blk[3 * f + 1]];
-            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) o[9 + i * 3 + j] = P.fac_swap[f] ? b1[j * 3 + i] : b1[i * 3 + j];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) o[9 + i * 3 + j] = P.fac_swap[f] ? b1[j * 3 + i] : b1[i * 3 + j];      // (rows a, columns b: for a factor with an asymmetric W that the reference enters as (b, a), the transpose of its J_b^T W J_a)
             memcpy(o + 18, &H[(size_t)9 * P.slot_blk[3 * f + 2]], 72);
             memcpy(o + 30, &H[(size_t)9 * P.slot_rhs[2 * f + 1]], 24);
         }

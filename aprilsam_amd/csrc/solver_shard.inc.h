@@ -198,6 +198,7 @@ static int shard_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *para
     if (!gp.host_idx.empty()) return -4;
     pack_states(gp, g, false);
     c.have_plan = false;                      // the pool layout is per rank: never reuse an upload made for another layout
+    orient_asymmetric(c, gp);
     prepare_plan(c, gp, g, false);
     const Plan &P = c.plan;
     { auto it = g_shard.find(param); if (it != g_shard.end()) { it->second->release(); g_shard.erase(it); } }
@@ -231,7 +232,7 @@ static int shard_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *para
     if (tab.empty()) tab.push_back(0);
     S.d_tab.need(tab.size());
     HIPCHECK(hipMemcpyAsync(S.d_tab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, gp.stream));
-    { size_t mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, diag_doubles(S.levels[l].n_big, S.levels[l].n_diag_slots)); c.d_diag.need(mx); }
+    { size_t mx = 1; for (int l = 0; l < P.nLevels; l++) mx = std::max(mx, diag_doubles(S.levels[l].n_big)); c.d_diag.need(mx); }
     // ---- factors owned by this rank's fronts, node ownership ----------------------------------------------------
     std::vector<int> fl;
     for (int f = 0; f < P.F; f++) if (P.fac_front[f] >= 0 && S.owner[P.fac_front[f]] == rank) fl.push_back(f);
@@ -365,8 +366,7 @@ static int shard_iterate_impl(april_graph_t *g, april_graph_cholesky_param_t *pa
             hipLaunchKernelGGL((k_linearize_t<false>), dim3((S.n_flist + TPB - 1) / TPB), dim3(TPB), 0, s, 0, S.n_flist, (const int *)S.d_flist.p, gp.d_fa.p, gp.d_fb.p,
                                gp.d_z.p, gp.d_W.p, gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, (int *)nullptr, (const double *)nullptr);
         for (int l = 0; l < P.nLevels; l++) {
-            c.la_next = 0;
-            enqueue_factor_level(c, S.levels[l], s, nop, nop0, g_opt.lookahead != 0, S.d_tab.p);
+            enqueue_factor_level(c, S.levels[l], s, nop, nop0, S.d_tab.p);
             if (S.up[l].empty() || !T) continue;
             bool any = false;
             for (const auto &x : S.up[l]) {

@@ -101,3 +101,20 @@ def write_vertex_edge_text(path, states, fa, fb, z, W):
             w = W[k]
             f.write("EDGE2 %d %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n" % (
                 fa[k], fb[k], z[k][0], z[k][1], z[k][2], w[0], w[1], w[4], w[8], w[2], w[5]))
+
+
+def as_loaded_with_correlations(W, seed, corr=0.04):
+    """Information matrices as the reference's text loader leaves them for an EDGE2 line with correlated information
+    (examples/aprilsam_demo.c:73-75): I12, I13, I23 go to W[1], W[2], W[5]; W[3], W[6], W[7] stay ZERO -- the matrix is not
+    symmetric as given, and the reference uses it as given (aprilsam.c:162,171,520).  The correlations are
+    `corr` x sqrt(W_ii W_jj) with random signs: small enough for the reference's system to stay positive definite (it walks
+    into a NULL factor otherwise, aprilsam.c:234-236).  Rows with fb < 0 semantics (priors) are the caller's to leave alone."""
+    rng = np.random.default_rng(seed)
+    W = np.array(W, float).reshape(-1, 9).copy()
+    d = np.sqrt(np.abs(W[:, [0, 4, 8]]))
+    sg = rng.choice([-1.0, 1.0], size=(len(W), 3)) * rng.uniform(0.5, 1.0, size=(len(W), 3))
+    W[:, 1] = corr * sg[:, 0] * d[:, 0] * d[:, 1]
+    W[:, 2] = corr * sg[:, 1] * d[:, 0] * d[:, 2]
+    W[:, 5] = corr * sg[:, 2] * d[:, 1] * d[:, 2]
+    W[:, 3] = 0.0; W[:, 6] = 0.0; W[:, 7] = 0.0
+    return W

@@ -64,15 +64,16 @@ def run_tutorial(lib, batch_update_only=False, nthreshold=100, delta_xy=0.1, del
 
 
 def run_demo(lib, arrays, batch_update_only=False, nthreshold=100, delta_xy=0.1, delta_theta=0.1,
-             max_poses=None, deterministic=True, record_states_every=0, on_step=None):
+             max_poses=None, deterministic=True, record_states_every=0, on_step=None, batch_every=0):
     """arrays = (states, fa, fb, z, W) of the LOADED graph (no prior). Returns dict with per-step chi2, ms,
-    batch fall-back flags and the final states."""
+    batch fall-back flags and the final states.  Beyond the demo: factors with fb < 0 are xytpos priors added with their pose;
+    batch_every = k > 0 calls the batch step at every k-th pose (a caller-made fall-back)."""
     states, fa, fb, z, W = arrays
     N = len(states) if max_poses is None else min(max_poses, len(states))
     # factors grouped by the pose at which the demo adds them (max node id), file order preserved
     by_pose = [[] for _ in range(N)]
     for k in range(len(fa)):
-        m = max(int(fa[k]), int(fb[k]))
+        m = max(int(fa[k]), int(fb[k]))          # (a prior, fb = -1: its own pose)
         if m < N:
             by_pose[m].append(k)
     g = lib.new_graph(); p = lib.new_param(nthreshold=nthreshold, delta_xy=delta_xy, delta_theta=delta_theta)
@@ -85,6 +86,9 @@ def run_demo(lib, arrays, batch_update_only=False, nthreshold=100, delta_xy=0.1,
         else:
             for f in by_pose[k]:
                 a, b = int(fa[f]), int(fb[f])
+                if b < 0:
+                    g.add_factor_xytpos(a, z[f], W[f])
+                    continue
                 if abs(a - b) == 1:                      # "odom" (aprilsam_demo.c:83-87,172-191)
                     if a < b:
                         g.set_state(b, _xyt_mul(g.states_of(a), z[f]), relinearize=True)
@@ -93,7 +97,7 @@ def run_demo(lib, arrays, batch_update_only=False, nthreshold=100, delta_xy=0.1,
                 g.add_factor_xyt(a, b, z[f], W[f])
         n_before = p.c.factor_num
         t0 = time.perf_counter()
-        if batch_update_only or k == 0:
+        if batch_update_only or k == 0 or (batch_every and k % batch_every == 0):
             g.cholesky(p); was_batch[k] = True
         else:
             if deterministic:

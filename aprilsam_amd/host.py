@@ -67,6 +67,7 @@ class SolverLib:
             d.aprilsam_amd_version.restype = C.c_char_p
             d.aprilsam_amd_get_stats.argtypes = [C.POINTER(abi.CholeskyParam), C.POINTER(abi.Stats)]
             d.aprilsam_amd_set_option.argtypes = [C.c_char_p, C.c_double]
+            d.aprilsam_amd_get_option.argtypes = [C.c_char_p, _dp]
             d.aprilsam_amd_last_error.argtypes = [C.c_char_p, C.c_int]
             d.aprilsam_amd_batch_resident.argtypes = [C.POINTER(abi.Graph), C.POINTER(abi.CholeskyParam),
                                                       C.c_int, _dp, _dp]
@@ -114,6 +115,29 @@ class SolverLib:
         rc = self.dll.aprilsam_amd_set_option(name.encode(), float(value))
         if rc != 0:
             raise ValueError(f"unknown option {name}")
+
+    def get_option(self, name):
+        v = C.c_double()
+        if self.dll.aprilsam_amd_get_option(name.encode(), C.byref(v)) != 0:
+            raise ValueError(f"unknown option {name}")
+        return v.value
+
+    def options(self, **kw):
+        """context manager: set the given options, restore what they were on the way out"""
+        lib = self
+
+        class _Scope:
+            def __enter__(self):
+                self.saved = {k: lib.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    lib.set_option(k, v)
+                return lib
+
+            def __exit__(self, *exc):
+                for k, v in self.saved.items():
+                    lib.set_option(k, v)
+                return False
+        return _Scope()
 
     def last_error(self):
         """(code, message) of the most recent failed call in this process; (0, "") when there was none"""
@@ -301,6 +325,18 @@ class Graph:
             nd.state[k] = xyt[k]
             if relinearize:
                 nd.l_point[k] = xyt[k]
+
+    def set_all_states(self, states, relinearize=False):
+        for i in range(self.n_nodes):
+            self.set_state(i, states[i], relinearize)
+
+    def set_all_W(self, W):
+        """edit the information matrices of all xyt / xytpos factors in place (W: [F, 9])"""
+        W = np.asarray(W, float).reshape(-1, 9)
+        for i in range(self.n_factors):
+            Wd = self.factor(i).u.W.contents.data
+            for k in range(9):
+                Wd[k] = W[i, k]
 
     # -- solver (aprilsam.h:268-281) -----------------------------------------------------------------
     def chi2(self):

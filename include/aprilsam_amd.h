@@ -262,8 +262,6 @@ void aprilsam_amd_clear_error(void);
  *   "device_timing"     1 = record per-stage HIP events (default 0)
  *   "trust_factor_cache" 1 = z/W of already-packed factors are treated as immutable: skips the per-call re-read and
  *                       comparison of every factor object (default 0: reference semantics, edits in place are seen)
- *   "block_factor"      0 = per-3x3-pivot elimination through LDS in the single-workgroup front kernel (default 1: 16 columns
- *                       at a time in registers)
  *   "small_lds_kb"      LDS budget (KiB) of the single-workgroup front kernel: fronts whose whole array fits run fully
  *                       in LDS, fronts whose own columns fit run in panel mode, the rest takes the multi-workgroup
  *                       path (default 156; 0 forces the multi-workgroup path everywhere)
@@ -273,14 +271,11 @@ void aprilsam_amd_clear_error(void);
  *                       several workgroups share a compute unit
  *   "small_threads", "tp_threads"  workgroup size of the single-workgroup front kernel (256 / 512 / 1024) on
  *                       latency-bound levels (default 1024) and on throughput levels (default 512)
- *   "syrk128_rows"      trailing updates at least this tall use the LDS-staged 128x128 MFMA kernel (default off)
  *   "schur_first"       small fronts in panel mode with at least this many update blocks store the Schur product into their update
  *                       columns first and add the factor blocks / children's update blocks afterwards (no zero fill, no atomics
  *                       for the product); default 40, 0 = never
  *   "syrk_small_tiles"  wide trailing updates of fewer 64x64 tiles than this use 32x32 tiles (four times the workgroups, a quarter of
  *                       the K loop each); default 320 = a quarter of a round of workgroups, 0 = never
- *   "syrk_variant"      wide trailing updates: 0 (default) = 5 waves per SIMD (2 K-steps of operands in flight, C read after the K
- *                       loop); 1 = the round-2/3 kernel (8 K-steps, C up front, 2 waves per SIMD)
  *   "syrk_xcd_order"    wide trailing updates of at least this many 64x64 tiles use the XCD-aware tile order (default 512 = one
  *                       round of workgroups; 0 = never, 1 = always)
  *   "batch_extend"      1 (default): april_graph_cholesky on a graph that only GREW since the last plan keeps the plan -- the
@@ -319,19 +314,9 @@ void aprilsam_amd_clear_error(void);
  *   "persist"           1 (default): the top levels of the elimination tree -- as many as hold at most "persist_max_fronts"
  *                       (default 240) single-workgroup fronts -- run as ONE launch per sweep, fronts synchronised by
  *                       per-front dependency flags; 0 = one launch per level
- *   "fused_panel"       0 = diagonal block and row solves of a multi-tile panel step as two kernels (default 1: one)
- *   "lookahead"         1 = wide trailing updates split, the far part on a side stream (default 0: measured no gain)
- *   "block_panels"      1 (default): multi-workgroup fronts run the four panel steps of a 128-column outer block as two launches --
- *                       the 128 x 128 diagonal block factored in LDS by one workgroup, the rows below solved against it on the
- *                       matrix cores (explicit inverses of its 32 x 32 diagonal blocks); 0 = one launch per 32-column panel
- *   "blk_backsolve"     1 (default, needs block_panels): multi-workgroup fronts are back-substituted 128 columns at a time by a chain
+ *   "blk_backsolve"     1 (default): multi-workgroup fronts are back-substituted 128 columns at a time by a chain
  *                       workgroup + helper workgroups, with the inverse diagonal blocks the factorisation left behind; 0 = one
  *                       workgroup per front, 32 columns at a time
- *   "tile_assembly"     1 = big fronts assembled window by window in LDS and stored once; default 0 (chunks of block columns, zero
- *                       fill + L2 atomics: measured faster although it moves 2.5 x the bytes)
- *   "left_panels"       (block_panels = 0) 1 (default): inside a 128-column outer block of a multi-workgroup front every panel step applies the
- *                       earlier panels' updates to its own 32 columns itself (MFMA, overlapped with the pivot chain) instead
- *                       of a "narrow" update launch after every panel; 0 = right-looking narrow updates
  *   "wave_backsolve"    1 (default): fronts whose L panel fits LDS (multi-level launch, latency-bound levels, incremental
  *                       steps) are back-substituted column-per-lane -- one in-register chain per 64 columns; 0 = the
  *                       per-32-column-block kernel everywhere
@@ -340,6 +325,8 @@ void aprilsam_amd_clear_error(void);
  *   "mem_cap_mb"        > 0: any single device buffer above this size is refused as if the device were out of memory
  *                       (error -11); 0 = off (default).  For testing the failure path */
 int aprilsam_amd_set_option(const char *name, double value);
+/* current value of an option (after the environment and any set_option call): 0, or -1 for an unknown name */
+int aprilsam_amd_get_option(const char *name, double *value);
 
 /* ---- device-resident benchmark/driver API: states stay in HBM between iterations -------------
  * aprilsam_amd_batch_resident() runs `iters` batch Gauss-Newton iterations back to back without

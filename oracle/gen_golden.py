@@ -8,6 +8,7 @@ arrays (inputs + expected outputs) so the tests can run where the reference tree
     python oracle/gen_golden.py            # everything except the slow 100k lattice
     python oracle/gen_golden.py --big      # also K=316 (config 4), ~2 minutes of reference CPU time
     python oracle/gen_golden.py --custom   # ONLY the foreign-factor scenario (tests/support/custom_scenario.py)
+    python oracle/gen_golden.py --asym     # ONLY the fixtures with information matrices that are not symmetric as given
 """
 import argparse
 import os
@@ -44,8 +45,45 @@ def batch_trace(ref, arrays, iters, keep_first=True):
     return out
 
 
+def ref_ordering(ref, p, n):
+    import ctypes as C
+    order = np.zeros(n, np.int32)
+    ref.dll.rs_param_ordering.argtypes = [C.c_void_p, C.c_void_p]
+    ref.dll.rs_param_ordering(p.ptr, order.ctypes.data)
+    return order
+
+
+def asym_fixtures(ref):
+    """Information matrices as the reference's loader leaves them when the file holds correlated information
+    (examples/aprilsam_demo.c:73-75: upper triangle filled, lower left zero).  The reference uses W as given and accumulates only the
+    upper triangle of its ORDERED matrix (aprilsam.c:171,520), so its normal equations depend on its own elimination order here:
+    the fixtures hold that order too (the oracle takes it as data)."""
+    from tests.support import asym_scenarios
+    # (a) batch: a seeded random pose graph with priors, 3 iterations
+    arr = asym_scenarios.batch_graph()
+    st, fa, fb, z, W = arr
+    g = ref.new_graph(); g.build_from_arrays(*arr); p = ref.new_param()
+    chi2 = [g.chi2()]; states = []; dxs = []
+    for _ in range(3):
+        g.cholesky(p); chi2.append(g.chi2()); states.append(g.states()); dxs.append(g.deltas())
+    order = ref_ordering(ref, p, len(st))
+    np.savez_compressed(os.path.join(GOLD, "asym_batch.npz"), states=st, fa=fa, fb=fb, z=z, W=W, chi2=np.array(chi2), ordering=order,
+                        states_after=np.array(states), dx=np.array(dxs))
+    p.destroy(); g.destroy()
+    print("asym batch: chi2", chi2)
+    # (b) incremental growth with loop closures and a batch step every 250 poses
+    arr = asym_scenarios.growth_graph()
+    res = harness.run_demo(ref, arr, deterministic=True, record_states_every=100, batch_every=asym_scenarios.GROWTH_BATCH_EVERY)
+    np.savez_compressed(os.path.join(GOLD, "asym_inc_demo.npz"), states=arr[0], fa=arr[1], fb=arr[2], z=arr[3], W=arr[4], chi2=res["chi2"],
+                        was_batch=res["was_batch"], final_states=res["final_states"],
+                        **{f"snap_{k}": v for k, v in res["snaps"].items()})
+    print("asym inc demo: final chi2", res["chi2"][-1], "batch steps", int(res["was_batch"].sum()) - 1, "loop closures",
+          int(((np.abs(arr[1] - arr[2]) > 1) & (arr[2] >= 0)).sum()))
+
+
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--big", action="store_true"); ap.add_argument("--custom", action="store_true")
+    ap.add_argument("--asym", action="store_true")
     a = ap.parse_args()
     import ctypes as C
     os.makedirs(GOLD, exist_ok=True)
@@ -61,6 +99,9 @@ def main():
         out3 = custom_scenario.run(ref, cl, triples=8)          # ... with three-pose factors (factor->nnodes == 3)
         np.savez_compressed(os.path.join(GOLD, "custom_factors3.npz"), **out3)
         print("custom factors incl. three-pose ones: chi2", out3["chi2"])
+        return
+    if a.asym:
+        asym_fixtures(ref)
         return
     prod = host.SolverLib()          # only its data generators are used here (lattice arrays)
 

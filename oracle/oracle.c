@@ -16,7 +16,10 @@
  *                         Tikhonov on the diagonal)
  *   ordering              node-level greedy minimum degree with explicit clique formation, the mechanism
  *                         of aprilsam.c:1148-1199 without its "recent poses last" constraint (results are
- *                         ordering independent to ~1e-10)
+ *                         ordering independent to ~1e-10) -- EXCEPT when a factor's W is not
+ *                         symmetric as given: the upper-triangle rule of aprilsam.c:171 then makes the normal
+ *                         equations depend on the order, and the *_ordered entry points take the reference's
+ *                         own order (param->ordering) as data (tests/golden/asym_*.npz)
  *   Cholesky              up-looking sparse Cholesky = the published CSparse algorithm the reference
  *                         calls at aprilsam.c:233-234 (cs_schol/cs_chol, csparse.c:462-512: elimination
  *                         tree, row reach, sparse triangular solve per row), restated from T. Davis,
@@ -270,13 +273,19 @@ static int row_reach(int n, const int *Ap, const int *Ai, int k, const int *pare
     return top;
 }
 
-int orc_solve_system(int N, const double *lp, const double *st_unary, int F, const int *fa, const int *fb,
-                     const double *z, const double *W, const double *lambda_node, double *dx,
-                     int *ordering_out, double *stats)
+/* order_in (position -> node, N ints) or NULL.  The solution of the normal equations does not depend on the elimination order -- but
+ * the normal equations themselves do when a factor's W is not symmetric AS GIVEN: only entries in the upper triangle of the ORDERED
+ * matrix are accumulated (aprilsam.c:171), so a factor (a, b) contributes J_a'W J_b when a is eliminated first and J_b'W J_a
+ * otherwise, which are transposes of each other only for a symmetric W.  For such inputs the reference's own order (param->ordering,
+ * aprilsam.c:999-1249; held in the golden fixtures) has to be supplied. */
+int orc_solve_system_ordered(int N, const double *lp, const double *st_unary, int F, const int *fa, const int *fb,
+                             const double *z, const double *W, const double *lambda_node, double *dx,
+                             const int *order_in, int *ordering_out, double *stats)
 {
     const int n = 3 * N;
     int *order = malloc(sizeof(int) * N), *idxs = malloc(sizeof(int) * N);
-    min_degree_order(N, F, fa, fb, order);
+    if (order_in) memcpy(order, order_in, sizeof(int) * N);
+    else min_degree_order(N, F, fa, fb, order);
     for (int i = 0; i < N; i++) idxs[order[i]] = 3 * i;                 /* aprilsam.c:141-148 */
     if (ordering_out) memcpy(ordering_out, order, sizeof(int) * N);
 
@@ -356,13 +365,26 @@ int orc_solve_system(int N, const double *lp, const double *st_unary, int F, con
     return rc;
 }
 
+int orc_solve_system(int N, const double *lp, const double *st_unary, int F, const int *fa, const int *fb,
+                     const double *z, const double *W, const double *lambda_node, double *dx,
+                     int *ordering_out, double *stats)
+{
+    return orc_solve_system_ordered(N, lp, st_unary, F, fa, fb, z, W, lambda_node, dx, NULL, ordering_out, stats);
+}
+
 int orc_batch_step(int N, double *states, int F, const int *fa, const int *fb, const double *z, const double *W,
                    double lambda, double *dx_out, double *stats)
+{
+    return orc_batch_step_ordered(N, states, F, fa, fb, z, W, lambda, NULL, dx_out, stats);
+}
+
+int orc_batch_step_ordered(int N, double *states, int F, const int *fa, const int *fb, const double *z, const double *W,
+                           double lambda, const int *order_in, double *dx_out, double *stats)
 {
     double *lp = malloc(sizeof(double) * 3 * N), *dx = malloc(sizeof(double) * 3 * N), *lam = malloc(sizeof(double) * N);
     memcpy(lp, states, sizeof(double) * 3 * N);                          /* relinearize, aprilsam.c:131-135 */
     for (int i = 0; i < N; i++) lam[i] = lambda > 0 ? lambda : 0;
-    int rc = orc_solve_system(N, lp, lp, F, fa, fb, z, W, lam, dx, NULL, stats);
+    int rc = orc_solve_system_ordered(N, lp, lp, F, fa, fb, z, W, lam, dx, order_in, NULL, stats);
     if (rc == 0) {
         for (int i = 0; i < N; i++) {                                    /* april_graph_xyt.c:302-314 */
             const double *d = dx + 3 * i;

@@ -23,6 +23,15 @@ int orc_solve_system(int N, const double *lp, const double *st_unary, int F, con
                      const double *z, const double *W, const double *lambda_node, double *dx,
                      int *ordering_out, double *stats);
 
+/* The same with the elimination order given (position -> node; NULL = the oracle's own min-degree order).  Needed only when some W is
+ * not symmetric as given: the reference accumulates the upper triangle of the ORDERED matrix with W as given (aprilsam.c:171), so its
+ * normal equations then depend on its order (param->ordering, held in the golden fixtures). */
+int orc_solve_system_ordered(int N, const double *lp, const double *st_unary, int F, const int *fa, const int *fb,
+                             const double *z, const double *W, const double *lambda_node, double *dx,
+                             const int *order_in, int *ordering_out, double *stats);
+int orc_batch_step_ordered(int N, double *states, int F, const int *fa, const int *fb, const double *z, const double *W,
+                           double lambda, const int *order_in, double *dx_out, double *stats);
+
 /* One batch Gauss-Newton step: l_point <- states; solve; states <- l_point + dx (theta wrapped, NaN rows
  * skipped).  Returns 0 / -1 as above. */
 int orc_batch_step(int N, double *states, int F, const int *fa, const int *fb, const double *z, const double *W,

@@ -33,6 +33,7 @@ class Oracle:
         d.orc_chi2.argtypes = [C.c_int, _dp, C.c_int, _ip, _ip, _dp, _dp]
         d.orc_solve_system.argtypes = [C.c_int, _dp, _dp, C.c_int, _ip, _ip, _dp, _dp, _dp, _dp, _ip, _dp]
         d.orc_batch_step.argtypes = [C.c_int, _dp, C.c_int, _ip, _ip, _dp, _dp, C.c_double, _dp, _dp]
+        d.orc_batch_step_ordered.argtypes = [C.c_int, _dp, C.c_int, _ip, _ip, _dp, _dp, C.c_double, _ip, _dp, _dp]
         d.orc_normal_equations_dense.argtypes = [C.c_int, _dp, _dp, C.c_int, _ip, _ip, _dp, _dp, C.c_double, _dp, _dp]
 
     @staticmethod
@@ -58,11 +59,15 @@ class Oracle:
         s, fa, fb, z, W = self._prep(states, fa, fb, z, W)
         return self.dll.orc_chi2(len(s), _d(s), len(fa), _i(fa), _i(fb), _d(z), _d(W))
 
-    def batch_step(self, states, fa, fb, z, W, lam=1e-4):
-        """returns (new_states, dx, stats[nnzL, sumsq]); raises on non-SPD"""
+    def batch_step(self, states, fa, fb, z, W, lam=1e-4, order=None):
+        """returns (new_states, dx, stats[nnzL, sumsq]); raises on non-SPD.  order: elimination order (position -> node) -- only matters,
+        and is then required for parity with the reference, when some W is not symmetric as given (oracle.h)"""
         s, fa, fb, z, W = self._prep(states, fa, fb, z, W)
         dx = np.zeros_like(s); stats = np.zeros(2)
-        rc = self.dll.orc_batch_step(len(s), _d(s), len(fa), _i(fa), _i(fb), _d(z), _d(W), lam, _d(dx), _d(stats))
+        if order is not None:
+            order = np.ascontiguousarray(order, np.int32)
+            assert len(order) == len(s)
+        rc = self.dll.orc_batch_step_ordered(len(s), _d(s), len(fa), _i(fa), _i(fb), _d(z), _d(W), lam, _i(order) if order is not None else None, _d(dx), _d(stats))
         if rc != 0:
             raise ArithmeticError("oracle: matrix not positive definite")
         return s, dx, stats
@@ -83,11 +88,11 @@ class Oracle:
         self.dll.orc_normal_equations_dense(len(lp), _d(lp), _d(lp), len(fa), _i(fa), _i(fb), _d(z), _d(W), lam, _d(A), _d(B))
         return A, B
 
-    def iterate(self, arrays, iters, lam=1e-4):
+    def iterate(self, arrays, iters, lam=1e-4, order=None):
         """chi2 trace [iters+1] and final states of `iters` batch steps"""
         s, fa, fb, z, W = self._prep(*arrays)
         chi2 = [self.chi2(s, fa, fb, z, W)]
         for _ in range(iters):
-            s, _, _ = self.batch_step(s, fa, fb, z, W, lam)
+            s, _, _ = self.batch_step(s, fa, fb, z, W, lam, order)
             chi2.append(self.chi2(s, fa, fb, z, W))
         return np.array(chi2), s

@@ -389,14 +389,14 @@ def test_malformed_and_unsupported_graphs_are_refused_without_abort(lib):
 # ---- plan cache vs options / edits ----------------------------------------------------------------------------------------
 def test_options_changed_on_a_param_with_a_cached_plan_force_a_replan(lib, oracle):
     """launch tables are built for the options in force at plan time and read again at enqueue time: toggling
-    block_panels / left_panels / fused_panel / small_lds_kb on a warm param (no graph replay, so the live enqueue code runs) must re-plan"""
+    blk_backsolve / syrk_small_tiles / small_lds_kb on a warm param (no graph replay, so the live enqueue code runs) must re-plan"""
     arr = lib.lattice_arrays(40)
     oc, ost = oracle.iterate(arr, 1)
     lib.set_option("use_graph", 0); lib.set_option("small_lds_kb", 0)
     try:
         g = lib.new_graph(); g.build_from_arrays(*arr); p = lib.new_param()
         st0 = g.states().copy()
-        for name, val in (("block_panels", 0), ("left_panels", 0), ("fused_panel", 0), ("left_panels", 1), ("small_lds_kb", 64), ("fused_panel", 1), ("block_panels", 1)):
+        for name, val in (("blk_backsolve", 0), ("syrk_small_tiles", 0), ("syrk_xcd_order", 1), ("small_lds_kb", 64), ("syrk_small_tiles", 320), ("blk_backsolve", 1), ("syrk_xcd_order", 512)):
             g.cholesky(p)
             assert p.stats()["not_spd"] == 0 and np.max(np.abs(g.states() - ost)) < 1e-6, name
             for i in range(g.n_nodes):
@@ -409,7 +409,7 @@ def test_options_changed_on_a_param_with_a_cached_plan_force_a_replan(lib, oracl
                 g.set_state(i, st0[i])
         p.destroy(); g.destroy()
     finally:
-        for name, val in (("use_graph", 1), ("small_lds_kb", 156), ("left_panels", 1), ("fused_panel", 1), ("block_panels", 1)):
+        for name, val in (("use_graph", 1), ("small_lds_kb", 156), ("blk_backsolve", 1), ("syrk_small_tiles", 320), ("syrk_xcd_order", 512)):
             lib.set_option(name, val)
 
 

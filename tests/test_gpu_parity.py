@@ -80,19 +80,21 @@ def test_tutorial_batch_mode_matches_reference_golden(lib):
 
 
 @pytest.mark.parametrize("opts", [dict(small_lds_kb=0), dict(small_lds_kb=48), dict(small_lds_kb=156), dict(panel_mode=0, small_lds_kb=64),
-                                  dict(small_threads=256), dict(small_threads=512), dict(tp_fronts=1, tp_lds_kb=8), dict(lookahead=1, small_lds_kb=0), dict(lookahead=1, small_lds_kb=0, use_graph=0), dict(syrk128_rows=64, small_lds_kb=0), dict(schur_first=1), dict(schur_first=1, small_lds_kb=48), dict(schur_first=1, persist=0, use_graph=0), dict(schur_first=8, leaf_nodes=40), dict(schur_first=0), dict(syrk_small_tiles=0, small_lds_kb=0), dict(syrk_small_tiles=1 << 30, small_lds_kb=0), dict(syrk_small_tiles=1 << 30, small_lds_kb=0, lookahead=1, syrk_xcd_order=1), dict(syrk_variant=1, small_lds_kb=0), dict(syrk_xcd_order=1, small_lds_kb=0), dict(syrk_xcd_order=1, syrk_variant=1, small_lds_kb=0, use_graph=0), dict(syrk_xcd_order=0, small_lds_kb=0),
-                                  dict(block_panels=0, small_lds_kb=0), dict(block_panels=0, small_lds_kb=48), dict(blk_backsolve=0, small_lds_kb=0), dict(tile_assembly=1, small_lds_kb=0), dict(tile_assembly=1, small_lds_kb=48, use_graph=0), dict(tile_assembly=1, small_lds_kb=0, leaf_nodes=64), dict(small_lds_kb=0, leaf_nodes=64), dict(small_lds_kb=0, leaf_nodes=4, use_graph=0),
-                                  dict(leaf_nodes=4), dict(leaf_nodes=40), dict(use_graph=0), dict(device_timing=1),
-                                  dict(block_factor=0), dict(block_factor=0, panel_mode=0, small_lds_kb=64), dict(fused_panel=0, small_lds_kb=0, block_panels=0),
-                                  dict(fused_panel=0, small_lds_kb=0, lookahead=1), dict(pin_last=12), dict(trust_factor_cache=1),
-                                  dict(linearize_staged_min=0), dict(persist=0), dict(persist_max_fronts=100000), dict(wave_backsolve=0), dict(wave_backsolve=0, persist=0), dict(left_panels=0, small_lds_kb=0, block_panels=0), dict(left_panels=0, small_lds_kb=48, block_panels=0)])
+                                  dict(small_threads=256), dict(small_threads=512), dict(tp_fronts=1, tp_lds_kb=8), dict(small_lds_kb=0, use_graph=0),
+                                  dict(schur_first=1), dict(schur_first=1, small_lds_kb=48), dict(schur_first=1, persist=0, use_graph=0), dict(schur_first=8, leaf_nodes=40), dict(schur_first=0),
+                                  dict(syrk_small_tiles=0, small_lds_kb=0), dict(syrk_small_tiles=1 << 30, small_lds_kb=0), dict(syrk_small_tiles=1 << 30, small_lds_kb=0, syrk_xcd_order=1),
+                                  dict(syrk_xcd_order=1, small_lds_kb=0), dict(syrk_xcd_order=0, small_lds_kb=0),
+                                  dict(blk_backsolve=0, small_lds_kb=0), dict(blk_backsolve=0, small_lds_kb=48), dict(small_lds_kb=0, leaf_nodes=64), dict(small_lds_kb=0, leaf_nodes=4, use_graph=0),
+                                  dict(leaf_nodes=4), dict(leaf_nodes=40), dict(use_graph=0), dict(device_timing=1), dict(pin_last=12), dict(trust_factor_cache=1),
+                                  dict(linearize_staged_min=0), dict(persist=0), dict(persist_max_fronts=100000), dict(wave_backsolve=0), dict(wave_backsolve=0, persist=0)])
 def test_every_kernel_path_agrees_with_oracle(lib, oracle, opts):
-    """force the multi-workgroup big-front path (outer-block panels -- diagonal block in LDS, row solves on the matrix cores -- and
-    the per-panel forms: left-looking, fused, two-kernel; with and without the LDS-staged MFMA tile kernel), small LDS budgets (more panel-mode and big fronts), panel mode off, the per-pivot elimination
-    instead of the in-register 16-column chain, other workgroup sizes and leaf sizes, the newest poses pinned into the root
-    front, no hipGraph, k_linearize with the LDS-staged write-out, no / all-level multi-level launches: same answers"""
-    defaults = dict(small_lds_kb=156, panel_mode=1, small_threads=1024, tp_fronts=1000, tp_lds_kb=64, lookahead=0, syrk128_rows=1 << 30, leaf_nodes=16, use_graph=1, device_timing=0,
-                    block_factor=1, fused_panel=1, pin_last=0, trust_factor_cache=0, linearize_staged_min=32768, persist=1, persist_max_fronts=240, wave_backsolve=1, left_panels=1, block_panels=1, blk_backsolve=1, tile_assembly=0, syrk_variant=0, syrk_xcd_order=512, schur_first=40, syrk_small_tiles=320)
+    """force the multi-workgroup big-front path (outer-block panels: diagonal block in LDS, row solves on the matrix cores, one wide
+    update per 128 columns in both tile sizes and tile orders), small LDS budgets (more panel-mode and big fronts), panel mode off,
+    other workgroup sizes and leaf sizes, the newest poses pinned into the root front, no hipGraph, k_linearize with the LDS-staged
+    write-out, no / all-level multi-level launches, both back-substitution forms: same answers.  (Round 5 removed the kernel variants
+    that earlier rounds had measured slower and retired -- per-panel forms, LDS-staged 128 x 128 update, tile assembly, side-stream
+    look-ahead, per-pivot elimination -- together with their options.)"""
+    saved = {k: lib.get_option(k) for k in opts}
     arr = datasets.random_pose_graph(700, 600, 21)
     oc, ost = oracle.iterate(arr, 2)
     try:
@@ -100,8 +102,8 @@ def test_every_kernel_path_agrees_with_oracle(lib, oracle, opts):
             lib.set_option(k, v)
         chi2, snaps, stats = run_batch(lib, arr, 2)
     finally:
-        for k in opts:
-            lib.set_option(k, defaults[k])
+        for k, v in saved.items():
+            lib.set_option(k, v)
     assert np.max(np.abs(chi2 - oc) / oc) < 1e-8
     assert np.max(np.abs(snaps[-1][0] - ost)) < STATE_ATOL
     if "device_timing" in opts:
@@ -116,13 +118,8 @@ def test_root_front_ending_in_a_partial_outer_block(lib, oracle):
     arr = datasets.random_pose_graph(3000, 1800, 102)
     oc, ost = oracle.iterate(arr, 2)
     for opts in (dict(), dict(small_lds_kb=0)):
-        try:
-            for k, v in opts.items():
-                lib.set_option(k, v)
+        with lib.options(**opts):
             chi2, snaps, stats = run_batch(lib, arr, 2)
-        finally:
-            for k in opts:
-                lib.set_option(k, 156)
         assert stats["max_front_rows"] > 1900
         assert np.max(np.abs(chi2 - oc) / oc) < 1e-8
         assert np.max(np.abs(snaps[-1][0] - ost)) < STATE_ATOL
@@ -318,15 +315,8 @@ def test_incremental_step_launch_forms_agree_with_the_reference_golden(lib, opts
     demo: identical fall-back schedule, chi^2 within 1e-6 of the reference golden at every step."""
     G = golden("m3500_inc_demo.npz")
     n = 420
-    defaults = {"inc_tail": 1, "inc_one": 1, "inc_multi": 1, "inc_inline": 1, "inc_one_spin": 1, "inc_one_threads": 512,
-                "inc_one_up": 3, "inc_one_dn": 4, "tail_poses": 28, "inc_update": 1}
-    for k, v in opts.items():
-        lib.set_option(k, v)
-    try:
+    with lib.options(**opts):
         res = harness.run_demo(lib, datasets.m3500_arrays(), max_poses=n, deterministic=True)
-    finally:
-        for k in opts:
-            lib.set_option(k, defaults[k])
     assert np.array_equal(res["was_batch"], G["was_batch"][:n])
     rel = np.abs(res["chi2"] - G["chi2"][:n]) / np.maximum(G["chi2"][:n], 1e-9)
     assert np.max(rel) < CHI2_RTOL, (int(np.argmax(rel)), float(np.max(rel)))

@@ -113,3 +113,22 @@ def test_oracle_matches_live_reference(oracle, reflib):
     chi2, st = oracle.iterate(arr, 3)
     assert np.allclose(chi2, ref, rtol=1e-8)
     assert np.max(np.abs(st - rst)) < 1e-7
+
+
+def test_information_matrices_not_symmetric_as_given(oracle):
+    """W as the reference's text loader leaves it for correlated information (upper triangle filled, lower zero,
+    examples/aprilsam_demo.c:73-75).  The reference accumulates only the upper triangle of its ORDERED matrix with W as given
+    (aprilsam.c:171): its normal equations depend on its elimination order, which the fixture holds.  With that order the
+    oracle reproduces the reference; with any other it must NOT (otherwise the fixture would not discriminate)."""
+    G = golden("asym_batch.npz")
+    arr = (G["states"], G["fa"], G["fb"], G["z"], G["W"])
+    W = G["W"]
+    assert np.any(W[:, 1] != W[:, 3]) and np.all(W[G["fb"] >= 0][:, [3, 6, 7]] == 0)
+    chi2, st = oracle.iterate(arr, 3, order=G["ordering"])
+    assert np.allclose(chi2, G["chi2"], rtol=1e-9)
+    assert np.max(np.abs(st - G["states_after"][-1])) < 1e-8
+    s1, dx1, _ = oracle.batch_step(G["states"], *arr[1:], order=G["ordering"])
+    assert np.max(np.abs(dx1 - G["dx"][0])) < 1e-8
+    # the oracle's own order: a different system
+    s2, dx2, _ = oracle.batch_step(G["states"], *arr[1:])
+    assert np.max(np.abs(dx2 - G["dx"][0])) > 1e-4

@@ -41,6 +41,18 @@ def test_reference_order_and_tree_restated_exactly(lib, reflib, case):
     p.destroy(); g.destroy()
 
 
+def test_restated_order_equals_the_order_in_the_asymmetric_w_fixture(lib):
+    """the library orients factors with an asymmetric W by the reference's elimination order: the restated order must equal the one the
+    reference used when the fixture was made (graph with priors on every fourth pose)"""
+    from tests.conftest import golden
+    G = golden("asym_batch.npz")
+    fa, fb = np.ascontiguousarray(G["fa"], np.int32), np.ascontiguousarray(G["fb"], np.int32)
+    N = len(G["states"])
+    mo = np.zeros(N, np.int32); mp = np.zeros(N, np.int32)
+    lib.dll.aprilsam_amd_reference_order(N, len(fa), _i(fa), _i(fb), _i(mo), _i(mp))
+    assert np.array_equal(mo, G["ordering"])
+
+
 def test_incremental_bookkeeping_follows_the_reference_step_by_step(lib, reflib, oracle):
     """first 260 poses of the M3500 demo (contains the first batch fall-back at 232 nodes)"""
     NST = 260
