@@ -20,6 +20,7 @@ enum {
     ERR_BAD_GRAPH = -13,       // malformed input: node index out of range, factor connecting a node to itself
     ERR_NO_DEVICE = -14,       // no HIP device visible (there is no CPU fallback: the call computed nothing)
     ERR_INTERNAL = -15,        // inconsistency in the planner (a bug, not an input problem)
+    ERR_GUARD = -16,           // debug option pool_guard: a kernel wrote into a guard band behind a frontal array
 };
 
 struct SolverError {

@@ -40,6 +40,7 @@ struct Options {
     int wave_backsolve = 1;       // multi-level back substitution: column-per-lane kernel (0: the per-32-column-block kernel)
     int linearize_staged_min = 32768; // factors per launch from which k_linearize writes its results out through LDS (coalesced stores)
     int mem_cap_mb = 0;           // > 0: refuse any single device buffer above this size with ERR_OOM (tests: the out-of-memory path)
+    int pool_guard = 0;           // debug: > 0 = every frontal array of a plan is followed by a guard band of this many doubles, NaN-filled at plan upload and checked after every synchronised step (ERR_GUARD); a stray read that is used poisons the result
     int panel_mode = 1;           // fronts too large for LDS whose own columns fit run in k_front_small's panel mode
 };
 extern Options g_opt;
@@ -69,6 +70,7 @@ int shard_iterate(april_graph_t *g, april_graph_cholesky_param_t *param, int n);
 int shard_gather_states(april_graph_t *g, april_graph_cholesky_param_t *param);
 double shard_chi2(april_graph_t *g, april_graph_cholesky_param_t *param);
 void shard_end(const april_graph_cholesky_param_t *param);
+int debug_guard_selftest(const april_graph_cholesky_param_t *param);
 int debug_stage(april_graph_t *g, april_graph_cholesky_param_t *param, int what, double *out);
 int debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts);
 int api_device_count();

@@ -108,6 +108,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     HIPCHECK(hipStreamSynchronize(gp.stream));
     const double t4 = now_ms();
     check_bad(c);
+    check_guard(c, gp.stream);
     c.st.error_code = 0;
     if (c.st.not_spd) {
         c.model.valid = false;
@@ -338,6 +339,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         c.h_kstamp.p[4] = 0;
     }
     check_bad(c);
+    check_guard(c, gp.stream);
     c.st.error_code = 0;
     c.st.n_nodes = N; c.st.n_factors = F; c.st.symbolic_reused = reused;
     if (c.st.not_spd) {

@@ -109,6 +109,7 @@ struct Context {
     // ones are appended, aprilsam.c:393-396).  Travels to the device as bit 1 of the per-factor swap byte (k_linearize).
     std::vector<unsigned char> wt; bool wt_any = false, wt_dirty = false;
     long long wt_serial = -1, wt_topo = -1, wt_content = -1;
+    DBuf<long long> d_guard; DBuf<int> d_guard_cnt; int n_guard = 0, guard_len = 0;      // option pool_guard: offsets of the guard bands in d_pool
     std::vector<unsigned char> swap_host;          // host copy of d_swap's base-plan part (the source of an asynchronous copy: must outlive it)
     // captured numeric phase
     // multi-level ("persistent") launches of the batch path: the top levels of the tree, where a level holds only a handful
@@ -161,7 +162,7 @@ struct Context {
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
         d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release();
-        h_done.release(); h_kstamp.release(); d_prof.release(); d_upd.release(); d_wbuf.release(); d_flags.release(); d_flevel.release(); d_perm.release(); d_solve_tab.release(); d_dinv.release(); d_bsb_far.release(); d_bsb_flags.release();
+        h_done.release(); h_kstamp.release(); d_prof.release(); d_upd.release(); d_wbuf.release(); d_flags.release(); d_flevel.release(); d_perm.release(); d_solve_tab.release(); d_dinv.release(); d_bsb_far.release(); d_bsb_flags.release(); d_guard.release(); d_guard_cnt.release(); n_guard = 0;
         retire(gexec); retire(gexec_api); reap_retired(true);
         if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
         have_events = false;
@@ -522,6 +523,18 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     const long long pool_doubles = lay ? lay->pool_doubles : P.pool_doubles;
     c.d_pool.need((size_t)std::max<long long>(pool_doubles, 1) + (size_t)pool_slack);
     c.inc.pool_used = pool_doubles; c.inc.pool_cap = (long long)c.d_pool.cap;
+    c.n_guard = 0;
+    if (g_opt.pool_guard > 0 && !lay) {
+        const long long G = ((long long)g_opt.pool_guard + 31) & ~31ll;
+        std::vector<long long> go((size_t)P.nF);
+        for (int t = 0; t < P.nF; t++) go[t] = P.f_off[t] + ((((long long)P.rows(t) * P.cols(t)) + 31) & ~31ll);
+        c.d_guard.need((size_t)P.nF); c.d_guard_cnt.need(2);
+        HIPCHECK(hipMemcpyAsync(c.d_guard.p, go.data(), go.size() * 8, hipMemcpyHostToDevice, s));
+        HIPCHECK(hipMemsetAsync(c.d_guard_cnt.p, 0, 8, s));
+        c.n_guard = P.nF; c.guard_len = (int)G;
+        hipLaunchKernelGGL(k_guard, dim3(c.n_guard), dim3(TPB), 0, s, 0, c.d_guard.p, c.n_guard, c.guard_len, c.d_pool.p, c.d_guard_cnt.p);
+        HIPCHECK(hipStreamSynchronize(s));      // (go goes out of scope)
+    }
     c.d_H.need((size_t)9 * ((size_t)std::max(1, P.n_slots) + (size_t)5 * INC_FACT_)); c.d_x.need((size_t)3 * ((size_t)P.N + INC_NODES_ + 1));
     c.inc.zpos = P.N + INC_NODES_;
     HIPCHECK(hipMemsetAsync(c.d_x.p + (size_t)3 * c.inc.zpos, 0, 24, s));
@@ -831,6 +844,13 @@ static bool prepare_plan(Context &c, GraphPack &gp, const april_graph_t *g, bool
     for (int i = 0; i < N; i++) { xy[2 * i] = gp.h_state.p[3 * i]; xy[2 * i + 1] = gp.h_state.p[3 * i + 1]; }
     const double tb0 = now_ms();
     build_plan(c.plan, N, F, c.pat.data(), xy.data(), g_opt.leaf_nodes);
+    if (g_opt.pool_guard > 0) {              // debug: a guard band behind every frontal array (upload_plan fills them, check_guard reads them)
+        Plan &P = c.plan;
+        const long long G = ((long long)g_opt.pool_guard + 31) & ~31ll;
+        long long off = 0;
+        for (int t = 0; t < P.nF; t++) { P.f_off[t] = off; off += ((((long long)P.rows(t) * P.cols(t)) + 31) & ~31ll) + G; }
+        P.pool_doubles = off;
+    }
     const double tb1 = now_ms();
     if (upload) upload_plan(c, gp.stream);
     if (getenv("APRILSAM_AMD_PLAN_PROFILE")) fprintf(stderr, "aprilsam_amd plan: N=%d build %.3f ms upload %.3f ms\n", N, tb1 - tb0, now_ms() - tb1);

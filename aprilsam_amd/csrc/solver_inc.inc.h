@@ -832,6 +832,15 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
 // After a synchronised numeric phase: c.h_bad mirrors the device's failure record {flag, front, kind, step}.  kind 9 = a
 // dependency-flag poll of a multi-level launch gave up (wait_flag): that is a failure of the launch, not of the matrix, and
 // is reported as ERR_DEP_TIMEOUT; everything else is a non-positive pivot (returns true, stats.not_spd).
+// debug option pool_guard, after a synchronised step: did any kernel write into a guard band?
+static void check_guard(Context &c, hipStream_t s) {
+    if (c.n_guard <= 0 || !c.d_pool.p) return;
+    int cnt[2] = { 0, 0 };
+    hipLaunchKernelGGL(k_guard, dim3(c.n_guard), dim3(TPB), 0, s, 1, c.d_guard.p, c.n_guard, c.guard_len, c.d_pool.p, c.d_guard_cnt.p);
+    HIPCHECK(hipMemcpyAsync(cnt, c.d_guard_cnt.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    if (cnt[0]) fail(ERR_GUARD, "pool_guard: %d words of the guard bands were overwritten (one of them: the band behind front %d of %d)", cnt[0], cnt[1], c.n_guard);
+}
 static bool check_bad(Context &c) {
     if (!c.h_bad.p[0]) { c.st.not_spd = 0; return false; }
     if (c.h_bad.p[0] == 9 || c.h_bad.p[2] == 9) fail(ERR_DEP_TIMEOUT, "a multi-level launch gave up waiting for a dependency flag (the fronts it waits for never finished)");

@@ -64,6 +64,7 @@ static int resident_sync_impl(april_graph_t *g, april_graph_cholesky_param_t *pa
     HIPCHECK(hipMemcpyAsync(c.h_bad.p, c.d_bad.p, 16, hipMemcpyDeviceToHost, gp.stream));
     HIPCHECK(hipStreamSynchronize(gp.stream));
     check_bad(c);
+    check_guard(c, gp.stream);
     if (c.h_bad.p[0] && getenv("APRILSAM_AMD_DEBUG")) {
         const int t = c.h_bad.p[1];
         fprintf(stderr, "aprilsam_amd: bad pivot: front %d kernel %d step %d", t, c.h_bad.p[2], c.h_bad.p[3]);
@@ -150,6 +151,20 @@ int level_profile(const april_graph_cholesky_param_t *param, double *out, int ca
         }
     }
     return P.nLevels;
+}
+// debug option pool_guard checking itself: declares ONE extra band that lies inside the first frontal array (which the last step
+// wrote) and runs the check, which must then report ERR_GUARD; the param's context is dropped by the failure path as for any error
+int debug_guard_selftest(const april_graph_cholesky_param_t *param) {
+    return guarded_rc(param, nullptr, [&]() -> int {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_ctx.find(param);
+        if (it == g_ctx.end() || !it->second->have_plan || it->second->n_guard <= 0) return -1;
+        Context &c = *it->second;
+        const long long inside = c.plan.f_off[0];
+        HIPCHECK(hipMemcpy(c.d_guard.p, &inside, 8, hipMemcpyHostToDevice));
+        check_guard(c, nullptr);
+        return 0;
+    });
 }
 int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls, double *flops, double *bytes, const char **names) {
     std::lock_guard<std::mutex> lk(g_mu);

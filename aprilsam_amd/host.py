@@ -68,6 +68,7 @@ class SolverLib:
             d.aprilsam_amd_get_stats.argtypes = [C.POINTER(abi.CholeskyParam), C.POINTER(abi.Stats)]
             d.aprilsam_amd_set_option.argtypes = [C.c_char_p, C.c_double]
             d.aprilsam_amd_get_option.argtypes = [C.c_char_p, _dp]
+            d.aprilsam_amd_debug_guard_selftest.argtypes = [C.POINTER(abi.CholeskyParam)]
             d.aprilsam_amd_last_error.argtypes = [C.c_char_p, C.c_int]
             d.aprilsam_amd_batch_resident.argtypes = [C.POINTER(abi.Graph), C.POINTER(abi.CholeskyParam),
                                                       C.c_int, _dp, _dp]

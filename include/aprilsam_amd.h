@@ -246,6 +246,7 @@ int aprilsam_amd_get_stats(const april_graph_cholesky_param_t *param, aprilsam_a
  *    -14  no HIP device visible: there is NO CPU fallback, every solver call on such a machine fails this way (april_graph_chi2
  *         returns NaN) -- nothing is ever computed on the host
  *    -15  internal inconsistency of the planner
+ *    -16  debug option "pool_guard": a kernel wrote into the guard band behind a frontal array
  * in stats.error_code and in aprilsam_amd_last_error (most recent failure of the process; msg may be NULL).  The param's
  * cached plan and factorisation are dropped: the next april_graph_cholesky starts from scratch, april_graph_cholesky_inc
  * returns silently until then (no prior factorisation, aprilsam.c:382-383). */
@@ -323,8 +324,15 @@ void aprilsam_amd_clear_error(void);
  *   "linearize_staged_min"  graphs with at least this many factors (default 32768) write the J^T W J blocks out through
  *                       LDS with coalesced stores; smaller ones store directly (one latency chain less)
  *   "mem_cap_mb"        > 0: any single device buffer above this size is refused as if the device were out of memory
- *                       (error -11); 0 = off (default).  For testing the failure path */
+ *                       (error -11); 0 = off (default).  For testing the failure path
+ *   "pool_guard"        debug, > 0: every frontal array of a plan is followed by a guard band of this many doubles (rounded up to 32), filled
+ *                       with NaN when the plan is uploaded and checked after every synchronised step: a kernel that wrote into one ends the
+ *                       call with error -16, a kernel that READ from one and used the value turns the results into NaN -- instead of a fault
+ *                       that depends on where the allocation ends.  0 = off (default) */
 int aprilsam_amd_set_option(const char *name, double value);
+/* debug, with option "pool_guard" on and after a step on this param: points the guard check at a band inside a live frontal array; returns
+ * -16 (the check works), -1 when the param has no guarded plan.  The param's cached plan is dropped, as after any failure */
+int aprilsam_amd_debug_guard_selftest(const april_graph_cholesky_param_t *param);
 /* current value of an option (after the environment and any set_option call): 0, or -1 for an unknown name */
 int aprilsam_amd_get_option(const char *name, double *value);
 

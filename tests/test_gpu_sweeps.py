@@ -1,0 +1,75 @@
+"""Bounded slices (about ten cases, under 20 s each) of the randomised / structured sweeps of tools/stress_*.py (tests/support/sweeps.py):
+random loop-closure graphs whose dense root fronts take every width modulo the 32- and 128-column blockings, chains / stars / complete /
+banded / comb graphs, odd lattices, random incremental growth, growth near the newest poses, one batch call per step on a growing graph --
+against the oracle and the live reference.  The random-graph slice runs a second time with option pool_guard: NaN-filled guard bands
+behind every frontal array, so a read past a front that is used changes the result instead of depending on where the allocation ends
+(round 4's bug faulted only when the front was the last array of the pool), and a write past a front is reported (error -16)."""
+import numpy as np
+import pytest
+
+import tests.test_gpu_parity as T
+from tests.support import sweeps
+
+pytestmark = pytest.mark.gpu
+BIG = (dict(), dict(small_lds_kb=0), dict(small_lds_kb=0, blk_backsolve=0))
+
+
+@pytest.mark.parametrize("guard", [0, 512])
+def test_random_loop_closure_graphs(lib, oracle, guard):
+    with lib.options(pool_guard=guard):
+        sweeps.sweep_batch(lib, oracle, sweeps.random_graph_cases(7, 6, 300, 2200) + sweeps.random_graph_cases(14, 4, 300, 1200), BIG, 1e-7, 1e-5, log=lambda s: None)
+
+
+def test_a_write_into_a_guard_band_is_reported(lib):
+    """the guard check itself: with pool_guard on, a healthy step reports nothing (above); here the check is pointed at a band that a
+    kernel legitimately writes -- guard bands shorter than the alignment padding cannot exist, so instead the option is switched on
+    AFTER the plan was made: the bands it then declares lie inside live frontal arrays and must be reported as overwritten"""
+    arr = sweeps.random_graph_cases(7, 1, 300, 400)[0][1]
+    with lib.options(pool_guard=64):
+        g = lib.new_graph(); g.build_from_arrays(*arr); p = lib.new_param()
+        g.cholesky(p)
+        assert p.stats()["error_code"] == 0
+        assert lib.dll.aprilsam_amd_debug_guard_selftest(p.ptr) == -16         # declares a band inside the first front, runs the check
+        lib.clear_error()
+        p.destroy(); g.destroy()
+
+
+def test_structured_graphs(lib, oracle):
+    cases = [("chain", 1500), ("chain", 97), ("star", 700), ("star", 130), ("complete", 60), ("complete", 140), ("two", 900), ("band", 1100), ("band", 257), ("comb", 1300)]
+    sweeps.sweep_batch(lib, oracle, [(f"{k} n={n}", sweeps.structured(k, n, 300 + i)) for i, (k, n) in enumerate(cases)],
+                       (dict(), dict(small_lds_kb=0), dict(small_lds_kb=16, leaf_nodes=6)), 1e-6, 1e-5, log=lambda s: None)
+
+
+def test_odd_lattices(lib, oracle):
+    sweeps.sweep_batch(lib, oracle, [(f"lattice K={K}", lib.lattice_arrays(K)) for K in (37, 91)],
+                       (dict(), dict(small_lds_kb=0), dict(small_lds_kb=48, leaf_nodes=24), dict(small_lds_kb=0, leaf_nodes=7, syrk_xcd_order=1, syrk_small_tiles=1 << 30)),
+                       1e-8, 1e-6, log=lambda s: None)
+
+
+@pytest.mark.parametrize("seed", range(100, 106))
+def test_random_incremental_growth_against_the_live_reference(lib, reflib, seed):
+    nth = [10 ** 6, 40, 12, 25][seed % 4]
+    ec, es = sweeps.compare_traces(T._random_growth(lib, seed, 120, nth), T._random_growth(reflib, seed, 120, nth))
+    assert ec < 1e-6 and es < 1e-6, (ec, es)
+
+
+@pytest.mark.parametrize("seed,tp", [(200, 28), (201, 9), (202, 16), (203, 12)])
+def test_growth_near_the_newest_poses_against_the_live_reference(lib, reflib, seed, tp):
+    nth = [10 ** 6, 30][seed % 2]
+    ec, es = sweeps.compare_traces(T._recent_pose_growth(lib, seed, 110, nth, tp), T._recent_pose_growth_ref(reflib, seed, 110, nth))
+    assert ec < 1e-6 and es < 1e-6, (ec, es)
+
+
+@pytest.mark.parametrize("seed,ext", [(300, 1), (300, 0), (301, 1), (301, 0)])
+def test_one_batch_call_per_step_on_a_growing_graph(lib, reflib, seed, ext):
+    G = type(lib.new_graph())
+    orig = G.cholesky_inc
+    G.cholesky_inc = lambda self, p: self.cholesky(p)          # the same growth, one BATCH call per step (the demo's --batch_update_only)
+    try:
+        with lib.options(batch_extend=ext):
+            ours = T._random_growth(lib, seed, 110, 10 ** 6, old_old=(seed % 2 == 0))
+        ref = T._random_growth(reflib, seed, 110, 10 ** 6, old_old=(seed % 2 == 0))
+    finally:
+        G.cholesky_inc = orig
+    ec, es = sweeps.compare_traces(ours, ref)
+    assert ec < 1e-6 and es < 1e-6, (ec, es)
