@@ -194,7 +194,7 @@ long long aprilsam_amd_plan_query(const aprilsam_amd_plan_t *plan, const char *w
     else if (k == "stats") v = { P.nF, P.nLevels, P.max_rows, (long long)P.nnzL, (long long)P.flops, (long long)P.pool_doubles };
     else { *out = nullptr; return -1; }
     *out = (long long *)malloc(sizeof(long long) * (v.size() + 1));
-    memcpy(*out, v.data(), sizeof(long long) * v.size());
+    if (!v.empty()) memcpy(*out, v.data(), sizeof(long long) * v.size());      // (an empty list has no data pointer: memcpy must not see it)
     return (long long)v.size();
 }
 

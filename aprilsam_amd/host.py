@@ -19,7 +19,8 @@ import numpy as np
 from . import abi
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-PRODUCT_LIB = os.path.join(_PKG_DIR, "lib", "libaprilsam_amd.so")
+# APRILSAM_AMD_LIB: another build of the same library (tools/sanitize_host.sh points it at the ASan / UBSan build of the host sources)
+PRODUCT_LIB = os.environ.get("APRILSAM_AMD_LIB") or os.path.join(_PKG_DIR, "lib", "libaprilsam_amd.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
