@@ -73,7 +73,22 @@ def asym_fixtures(ref):
     print("asym batch: chi2", chi2)
     # (b) incremental growth with loop closures and a batch step every 250 poses
     arr = asym_scenarios.growth_graph()
-    res = harness.run_demo(ref, arr, deterministic=True, record_states_every=100, batch_every=asym_scenarios.GROWTH_BATCH_EVERY)
+    nan_steps = []
+
+    def watch(k, p, wb):          # a NaN delta = the reference took the square root of a negative pivot: not a problem to pin anything against
+        if np.isnan(watch.g.deltas()).any():
+            nan_steps.append(k)
+    G_ = type(ref.new_graph())
+    orig_init = G_.__init__
+
+    def grab(self, *a, **kw):
+        orig_init(self, *a, **kw); watch.g = self
+    G_.__init__ = grab
+    try:
+        res = harness.run_demo(ref, arr, deterministic=True, record_states_every=100, batch_every=asym_scenarios.GROWTH_BATCH_EVERY, on_step=watch)
+    finally:
+        G_.__init__ = orig_init
+    assert not nan_steps, f"the reference produced NaN deltas at steps {nan_steps[:10]}: ill-posed scenario"
     np.savez_compressed(os.path.join(GOLD, "asym_inc_demo.npz"), states=arr[0], fa=arr[1], fb=arr[2], z=arr[3], W=arr[4], chi2=res["chi2"],
                         was_batch=res["was_batch"], final_states=res["final_states"],
                         **{f"snap_{k}": v for k, v in res["snaps"].items()})

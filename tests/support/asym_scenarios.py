@@ -8,7 +8,11 @@ tests/golden/asym_*.npz; the tests only read the fixtures.
 
 The graphs carry xytpos priors on every few poses: with W used as given the reference's matrix is J'SJ + (a symmetric term of
 the size of the correlations x the lever arm between the poses), and a pose graph held by ONE prior has eigenvalues of 1e-4
-(M3500) that such a term drives negative -- the reference then walks into the NULL factor cs_chol returns (aprilsam.c:234-236).
+(M3500) that such a term drives negative -- the reference then walks into the NULL factor cs_chol returns (aprilsam.c:234-236).  Its INCREMENTAL factorisation does not even
+notice: smatd_chol_inc_tr takes the square root of a negative pivot, every delta becomes NaN, xyt_node_update skips every pose
+(april_graph_xyt.c:302-314) and the run carries on with frozen states -- a first version of the growth scenario (a prior on every fifth
+pose) did exactly that from its eighth pose on, where this library reports "not positive definite" and recovers at the next step.
+gen_golden.py therefore asserts that no step of the reference run produced a NaN delta: the fixture is a well-posed problem.
 """
 import numpy as np
 
@@ -27,7 +31,7 @@ def batch_graph(n=300, extra=200, seed=11, spread=4.0, corr=0.05, prior_every=4)
             np.vstack([z, pz]), np.vstack([W, pW]))
 
 
-def growth_graph(n=800, corr=0.05, prior_every=5):
+def growth_graph(n=800, corr=0.05, prior_every=2):
     """the first n poses of M3500 (loop closures included), its diagonal W given loader-style correlations, for harness.run_demo"""
     s0, a0, b0, z0, W0 = datasets.m3500_arrays()
     keep = np.maximum(a0, b0) < n
