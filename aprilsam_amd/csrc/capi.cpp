@@ -57,6 +57,8 @@ double april_graph_chi2(april_graph_t *graph) { return asam::graph_chi2(graph); 
 
 int aprilsam_amd_device_count(void) { return asam::api_device_count(); }
 int aprilsam_amd_set_device(int device) { return asam::api_set_device(device); }
+int aprilsam_amd_param_set_device(const april_graph_cholesky_param_t *param, int slot) { return asam::api_param_set_device(param, slot); }
+int aprilsam_amd_param_get_device(const april_graph_cholesky_param_t *param) { return asam::api_param_get_device(param); }
 int aprilsam_amd_set_option(const char *name, double value) { return asam::api_set_option(name, value); }
 int aprilsam_amd_debug_guard_selftest(const april_graph_cholesky_param_t *param) { return asam::debug_guard_selftest(param); }
 int aprilsam_amd_get_option(const char *name, double *value) { return asam::api_get_option(name, value); }

@@ -79,6 +79,8 @@ struct Plan;
 void shard_map(const Plan &P, int world, std::vector<int> &owner, std::vector<char> &top, std::vector<long long> &xfer, std::vector<long long> &bcast);
 std::vector<long long> shard_critical_path(const Plan &P, int world, const std::vector<int> &owner, const std::vector<char> &top);
 int api_set_device(int d);
+int api_param_set_device(const april_graph_cholesky_param_t *param, int slot);
+int api_param_get_device(const april_graph_cholesky_param_t *param);
 int api_set_option(const char *name, double v);
 int api_get_option(const char *name, double *v);
 

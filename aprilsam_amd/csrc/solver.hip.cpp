@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <atomic>
 #include <mutex>
@@ -88,15 +89,51 @@ static void load_env_options() {
     });
 }
 
-static int g_device = -1;
+// ---- devices, slots and locks -------------------------------------------------------------------------------------------------
+// A param (and the pack of the graph it is called with) is bound to a device SLOT: aprilsam_amd_param_set_device, default = the
+// process default (aprilsam_amd_set_device / LOCAL_RANK / 0).  Slot s runs on HIP device s % device_count: on a node with N devices
+// the slots 0 .. N-1 ARE the devices, and more slots than devices share devices.  Every entry point takes the lock of ITS slot
+// (SlotLock) and makes that slot's device current on the calling thread: calls bound to different slots run concurrently -- one C
+// process can drive N contexts on N devices from N threads -- calls bound to the same slot are serialised (as before: one lock).
+// What is shared by all slots is guarded separately: the registries (param -> context, graph -> pack, param -> shard state: a
+// lock per operation, node-based maps so that an element is not moved by another key's insertion), the planner's thread pool
+// (symbolic.cpp: one plan at a time), the last-error record (errors.cpp).  The options (aprilsam_amd_set_option) are process-global
+// and are meant to be set while no call is in flight.
+constexpr int MAX_SLOTS = 64;
+static int g_device = -1;                         // the process default slot
+static std::mutex g_slot_mu[MAX_SLOTS];
+static thread_local int t_slot = 0;               // slot of the call in progress on this thread
 static int device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+static int physical_device(int slot) { const int n = device_count(); return n > 0 ? slot % n : 0; }
+template <class V> struct Registry {             // std::map: iterators and elements stay put when OTHER keys come and go
+    using Map = std::map<const void *, std::unique_ptr<V>>;
+    Map m; mutable std::mutex mu;
+    typename Map::iterator find(const void *k) { std::lock_guard<std::mutex> lk(mu); return m.find(k); }
+    typename Map::iterator end() { return m.end(); }
+    std::pair<typename Map::iterator, bool> emplace(const void *k, std::unique_ptr<V> v) { std::lock_guard<std::mutex> lk(mu); return m.emplace(k, std::move(v)); }
+    void erase(typename Map::iterator it) { std::lock_guard<std::mutex> lk(mu); m.erase(it); }
+    void put(const void *k, std::unique_ptr<V> v) { std::lock_guard<std::mutex> lk(mu); m[k] = std::move(v); }
+    template <class F> void for_each(F &&f) { std::lock_guard<std::mutex> lk(mu); for (auto &kv : m) f(*kv.second); }
+};
+static std::map<const void *, int> g_param_slot; static std::mutex g_param_slot_mu;      // aprilsam_amd_param_set_device
+static int default_slot() { return g_device < 0 ? 0 : g_device % MAX_SLOTS; }
+static int slot_of_graph(const void *g);          // solver_pack.inc.h: the slot its pack lives on, or -1
+static int slot_for(const void *param, const void *g) {
+    if (param) { std::lock_guard<std::mutex> lk(g_param_slot_mu); auto it = g_param_slot.find(param); if (it != g_param_slot.end()) return it->second; }
+    if (!param && g) { const int s = slot_of_graph(g); if (s >= 0) return s; }
+    return default_slot();
+}
+struct SlotLock {
+    int slot; std::unique_lock<std::mutex> lk;
+    SlotLock(const void *param, const void *g) : slot(slot_for(param, g)), lk(g_slot_mu[slot]) { t_slot = slot; if (device_count() > 0) (void)hipSetDevice(physical_device(slot)); }
+};
+static std::once_flag g_dev_once;
 static void ensure_device() {
-    static std::once_flag once;
-    std::call_once(once, [] {           // (an exception leaves the flag unset: the next call looks again)
+    std::call_once(g_dev_once, [] {
         load_env_options();
         int n = device_count();
         if (n <= 0) fail(ERR_NO_DEVICE, "no HIP device visible: the april_graph_cholesky* / april_graph_chi2 entry points of "
@@ -106,7 +143,6 @@ static void ensure_device() {
             g_device = lr ? atoi(lr) % n : 0;
         }
     });
-    HIPCHECK(hipSetDevice(g_device));
 }
 
 // grow-only device / pinned-host buffers.  A failed allocation leaves the buffer empty (never dangling) and throws ERR_OOM;
@@ -269,6 +305,15 @@ int api_set_device(int d) {
     g_device = d;
     return 0;
 }
+// bind a param (and, through it, the pack of the graph it is called with) to a device slot; whatever the param held is dropped
+int api_param_set_device(const april_graph_cholesky_param_t *param, int slot) {
+    if (!param || slot < 0 || slot >= MAX_SLOTS) return -1;
+    drop_context(param);                            // (under the lock of the slot it was on)
+    std::lock_guard<std::mutex> lk(g_param_slot_mu);
+    g_param_slot[param] = slot;
+    return 0;
+}
+int api_param_get_device(const april_graph_cholesky_param_t *param) { return physical_device(slot_for(param, nullptr)); }
 int api_set_option(const char *name, double v) {
     load_env_options();
     const OptionDef *d = name ? find_option(name) : nullptr;

@@ -162,7 +162,7 @@ void batch_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     guarded(param, g, [&] {
         if (!param->nreordering) fail(ERR_UNSUPPORTED, "april_graph_cholesky: param->nreordering == 0 (the reference asserts, aprilsam.c:372-374)");
         ensure_device();
-        std::lock_guard<std::mutex> lk(g_mu);
+        SlotLock lk(param, g);
         batch_impl(g, param);
     });
 }
@@ -239,7 +239,7 @@ void inc_step(april_graph_t *g, april_graph_cholesky_param_t *param) {
     guarded(param, g, [&] { inc_impl(g, param); });
 }
 static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, g);
     {
         auto it = g_ctx.find(param);
         if (it == g_ctx.end() || !it->second->have_fact) return;         // aprilsam.c:382-383 (no prior chol)
@@ -473,7 +473,7 @@ static void apply_visits(Context &c, GraphPack &gp, april_graph_t *g, april_grap
 void inc_solve_only(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (zsize(g->nodes) == 0) return;
     guarded(param, g, [&] {
-        std::lock_guard<std::mutex> lk(g_mu);
+        SlotLock lk(param, g);
         auto it = g_ctx.find(param);
         if (it == g_ctx.end() || !it->second->have_fact || !param->nreordering) return;        // aprilsam.c:580
         ensure_device();
@@ -513,7 +513,7 @@ double graph_chi2(april_graph_t *g) {
 }
 static double chi2_impl(april_graph_t *g) {
     ensure_device();
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(nullptr, g);
     GraphPack &gp = pack_for(g);
     pack_factors(gp, g);
     pack_states(gp, g, false);

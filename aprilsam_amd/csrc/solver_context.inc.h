@@ -170,10 +170,10 @@ struct Context {
         k_ev.clear();
     }
 };
-static std::unordered_map<const void *, std::unique_ptr<Context>> g_ctx;
+static Registry<Context> g_ctx;
 
 static void forget_stream(hipStream_t s) {
-    for (auto &kv : g_ctx) if (kv.second->graph_stream == s) kv.second->graph_stream = nullptr;
+    g_ctx.for_each([&](Context &c) { if (c.graph_stream == s) c.graph_stream = nullptr; });
 }
 
 static Context &ctx_for(const april_graph_cholesky_param_t *p) {
@@ -182,12 +182,12 @@ static Context &ctx_for(const april_graph_cholesky_param_t *p) {
     return *it->second;
 }
 void drop_context(const april_graph_cholesky_param_t *p) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(p, nullptr);
     auto it = g_ctx.find(p);
     if (it != g_ctx.end()) { it->second->release(); g_ctx.erase(it); }
 }
 bool get_stats(const april_graph_cholesky_param_t *p, aprilsam_amd_stats_t *out) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(p, nullptr);
     auto it = g_ctx.find(p);
     if (it == g_ctx.end()) return false;
     *out = it->second->st;
@@ -207,7 +207,7 @@ static void on_failure(const april_graph_cholesky_param_t *param, const april_gr
     set_last_error(code, msg);
     fprintf(stderr, "aprilsam_amd: ERROR %d: %s -- node states left untouched\n", code, msg.c_str());
     fflush(stderr);
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, g);
     (void)hipGetLastError();
     if (g) {
         auto it = g_packs.find(g);
@@ -233,7 +233,7 @@ static void on_failure(const april_graph_cholesky_param_t *param, const april_gr
         if (it != g_ctx.end()) { st = it->second->st; it->second->release(); }
         auto fresh = std::make_unique<Context>();
         fresh->st = st; fresh->st.error_code = code; fresh->st.not_spd = 0;
-        g_ctx[param] = std::move(fresh);
+        g_ctx.put(param, std::move(fresh));
     }
 }
 template <class Fn> static void guarded(const april_graph_cholesky_param_t *param, const april_graph_t *g, Fn &&fn) {
@@ -554,8 +554,8 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
 }
 
 static void set_small_attr() {
-    static std::once_flag once;
-    std::call_once(once, [] {
+    static std::once_flag once[MAX_SLOTS];          // (function attributes are kept per device)
+    std::call_once(once[physical_device(t_slot) % MAX_SLOTS], [] {
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHECK(hipFuncSetAttribute((const void *)k_front_small<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

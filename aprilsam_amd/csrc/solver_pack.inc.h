@@ -3,9 +3,10 @@
 // ------------------------------------------------------------------------------------------------------
 // packed graph (SoA, host pinned + device) — one per april_graph_t pointer
 // ------------------------------------------------------------------------------------------------------
-static long long g_pack_serial = 0;
+static std::atomic<long long> g_pack_serial{ 0 };
 static void forget_stream(hipStream_t s);      // solver_context.inc.h: no context may record an event on a stream that is about to be destroyed
 struct GraphPack {
+    int slot = 0;                      // device slot the pack's buffers and stream live on (solver.hip.cpp: SlotLock)
     const long long serial = ++g_pack_serial;      // captured hipGraphs are keyed by it: a pack freed and another allocated at the same addresses must not match
     int N = 0, F = 0;                  // packed counts (F: packed factor entries, see pack_factors)
     int Fg = 0;                        // graph factors packed (== F unless a factor has more than two nodes)
@@ -53,20 +54,27 @@ struct GraphPack {
     }
 };
 
-static std::mutex g_mu;
-static std::unordered_map<const void *, std::unique_ptr<GraphPack>> g_packs;
+static Registry<GraphPack> g_packs;
 
+static int slot_of_graph(const void *g) {
+    auto it = g_packs.find(g);
+    return it == g_packs.end() ? -1 : it->second->slot;
+}
+// the pack of a graph, on the slot of the call in progress (a pack left behind on another slot by an earlier call moves: dropped there,
+// rebuilt here -- one graph is driven from one slot at a time)
 static GraphPack &pack_for(const april_graph_t *g) {
     auto it = g_packs.find(g);
+    if (it != g_packs.end() && it->second->slot != t_slot) { it->second->release(); g_packs.erase(it); it = g_packs.end(); }
     if (it == g_packs.end()) {
         auto p = std::make_unique<GraphPack>();
+        p->slot = t_slot;
         HIPCHECK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
         it = g_packs.emplace(g, std::move(p)).first;
     }
     return *it->second;
 }
 void drop_graph_pack(const april_graph_t *g) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(nullptr, g);
     auto it = g_packs.find(g);
     if (it != g_packs.end()) { it->second->release(); g_packs.erase(it); }
 }

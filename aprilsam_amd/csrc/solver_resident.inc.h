@@ -8,7 +8,7 @@ int resident_begin(april_graph_t *g, april_graph_cholesky_param_t *param) { retu
 static int resident_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0) return -1;
     ensure_device();
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, g);
     Context &c = ctx_for(param);
     GraphPack &gp = pack_for(g);
     pack_factors(gp, g);
@@ -31,14 +31,13 @@ static int resident_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *p
 static int resident_steps_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int n, int mode);
 int resident_steps(april_graph_t *g, april_graph_cholesky_param_t *param, int n, int mode) { return guarded_rc(param, g, [&] { return resident_steps_impl(g, param, n, mode); }); }
 static int resident_steps_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int n, int mode) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, g);
     auto it = g_ctx.find(param);
     if (it == g_ctx.end() || !it->second->have_plan) return -1;
     Context &c = *it->second;
     GraphPack &gp = pack_for(g);
     hipStream_t s = gp.stream;
     const int N = gp.N;
-    HIPCHECK(hipSetDevice(g_device));
     set_small_attr();
     gp.mirror_sync = false;                           // (states move on the device only)
     for (int i = 0; i < n; i++) {
@@ -56,7 +55,7 @@ static int resident_steps_impl(april_graph_t *g, april_graph_cholesky_param_t *p
 static int resident_sync_impl(april_graph_t *g, april_graph_cholesky_param_t *param);
 int resident_sync(april_graph_t *g, april_graph_cholesky_param_t *param) { return guarded_rc(param, g, [&] { return resident_sync_impl(g, param); }); }
 static int resident_sync_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, g);
     auto it = g_ctx.find(param);
     if (it == g_ctx.end()) return -1;
     Context &c = *it->second;
@@ -80,13 +79,13 @@ double resident_chi2(april_graph_t *g) {
     return out;
 }
 static double resident_chi2_impl(april_graph_t *g) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(nullptr, g);
     return device_chi2(pack_for(g));
 }
 static int resident_end_impl(april_graph_t *g, april_graph_cholesky_param_t *param);
 int resident_end(april_graph_t *g, april_graph_cholesky_param_t *param) { return guarded_rc(param, g, [&] { return resident_end_impl(g, param); }); }
 static int resident_end_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, g);
     auto it = g_ctx.find(param);
     if (it == g_ctx.end()) return -1;
     Context &c = *it->second;
@@ -134,7 +133,7 @@ int batch_resident(april_graph_t *g, april_graph_cholesky_param_t *param, int it
 // back substitution), fronts, fronts on the multi-workgroup path, widest own part (scalar columns), sum c_j^2 flops.  A
 // multi-level launch is booked on its first level.  out: 6 doubles per level; returns the number of levels.
 int level_profile(const april_graph_cholesky_param_t *param, double *out, int cap_levels) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, nullptr);
     auto it = g_ctx.find(param);
     if (it == g_ctx.end() || !it->second->have_plan) return -1;
     Context &c = *it->second;
@@ -156,7 +155,7 @@ int level_profile(const april_graph_cholesky_param_t *param, double *out, int ca
 // wrote) and runs the check, which must then report ERR_GUARD; the param's context is dropped by the failure path as for any error
 int debug_guard_selftest(const april_graph_cholesky_param_t *param) {
     return guarded_rc(param, nullptr, [&]() -> int {
-        std::lock_guard<std::mutex> lk(g_mu);
+        SlotLock lk(param, nullptr);
         auto it = g_ctx.find(param);
         if (it == g_ctx.end() || !it->second->have_plan || it->second->n_guard <= 0) return -1;
         Context &c = *it->second;
@@ -167,7 +166,7 @@ int debug_guard_selftest(const april_graph_cholesky_param_t *param) {
     });
 }
 int kernel_profile(const april_graph_cholesky_param_t *param, double *ms, long long *calls, double *flops, double *bytes, const char **names) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, nullptr);
     auto it = g_ctx.find(param);
     if (it == g_ctx.end() || !it->second->have_plan) return -1;
     Context &c = *it->second;
@@ -226,7 +225,7 @@ int debug_stage(april_graph_t *g, april_graph_cholesky_param_t *param, int what,
 static int debug_stage_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int what, double *out) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0) return -1;
     ensure_device();
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, g);
     Context &c = ctx_for(param);
     GraphPack &gp = pack_for(g);
     pack_factors(gp, g);
@@ -295,7 +294,7 @@ static int debug_stage_impl(april_graph_t *g, april_graph_cholesky_param_t *para
 // debug: copy the per-front clock stamps (8 per front) written when APRILSAM_AMD_KPROF is set
 int debug_front_times(const april_graph_cholesky_param_t *param, long long *out, int n_fronts) {
     return guarded_rc(param, nullptr, [&]() -> int {
-        std::lock_guard<std::mutex> lk(g_mu);
+        SlotLock lk(param, nullptr);
         auto it = g_ctx.find(param);
         if (it == g_ctx.end() || !it->second->d_prof.p) return -1;
         HIPCHECK(hipDeviceSynchronize());

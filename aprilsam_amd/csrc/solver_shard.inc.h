@@ -112,8 +112,8 @@ struct ShardState {
     std::unique_ptr<Transport> tr;
     void release() { d_tab.release(); d_flist.release(); d_nown.release(); d_send.release(); d_recv.release(); d_scratch.release(); tr.reset(); }
 };
-static std::unordered_map<const void *, std::unique_ptr<ShardState>> g_shard;
-static void drop_shard_state(const void *param) {           // (failure path; g_mu held)
+static Registry<ShardState> g_shard;
+static void drop_shard_state(const void *param) {           // (failure path; the slot lock is held)
     auto it = g_shard.find(param);
     if (it != g_shard.end()) { it->second->release(); g_shard.erase(it); }
 }
@@ -191,7 +191,7 @@ int shard_begin(april_graph_t *g, april_graph_cholesky_param_t *param, int rank,
 static int shard_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int rank, int world) {
     if (zsize(g->nodes) == 0 || zsize(g->factors) == 0 || world < 1 || rank < 0 || rank >= world) return -1;
     ensure_device();
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, g);
     Context &c = ctx_for(param);
     GraphPack &gp = pack_for(g);
     pack_factors(gp, g);
@@ -202,7 +202,8 @@ static int shard_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *para
     prepare_plan(c, gp, g, false);
     const Plan &P = c.plan;
     { auto it = g_shard.find(param); if (it != g_shard.end()) { it->second->release(); g_shard.erase(it); } }
-    auto &S = *(g_shard[param] = std::make_unique<ShardState>());
+    g_shard.put(param, std::make_unique<ShardState>());
+    auto &S = *g_shard.find(param)->second;
     S.rank = rank; S.world = world;
     shard_map(P, world, S.owner, S.top, S.xfer, S.bcast);
     // ---- pool layout: owned fronts in plan order, then the ghosts of remote children -------------------------------
@@ -268,7 +269,7 @@ static int shard_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *para
 // what: 0 -> {levels, fronts, nodes, pool doubles of this rank, pool doubles of the whole plan}, 1 -> xfer (6 per entry),
 // 2 -> bcast (5 per entry), 3 -> owner per front.  Returns count written (or needed if out == null)
 long long shard_info(const april_graph_cholesky_param_t *param, int what, long long *out, long long cap) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, nullptr);
     auto it = g_shard.find(param); auto ic = g_ctx.find(param);
     if (it == g_shard.end() || ic == g_ctx.end()) return -1;
     const ShardState &S = *it->second;
@@ -297,7 +298,7 @@ static int shard_comm_init_rccl_impl(const april_graph_cholesky_param_t *param, 
 int shard_comm_init_rccl(const april_graph_cholesky_param_t *param, const char *id128) { return guarded_rc(param, nullptr, [&] { return shard_comm_init_rccl_impl(param, id128); }); }
 static int shard_comm_init_rccl_impl(const april_graph_cholesky_param_t *param, const char *id128) {
     ensure_device();
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, nullptr);
     auto it = g_shard.find(param);
     if (it == g_shard.end()) return -1;
     if (!g_rccl.load()) return -5;
@@ -305,7 +306,7 @@ static int shard_comm_init_rccl_impl(const april_graph_cholesky_param_t *param, 
     auto T = std::make_unique<RcclTransport>();
     ncclUniqueId id;
     memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
-    HIPCHECK(hipSetDevice(g_device));
+    
     const ncclResult_t r = g_rccl.CommInitRank(&T->comm, S.world, id, S.rank);
     if (r != ncclSuccess) { fprintf(stderr, "aprilsam_amd: ncclCommInitRank failed: %s\n", g_rccl.GetErrorString(r)); return -6; }
     S.tr = std::move(T);
@@ -315,11 +316,11 @@ static int shard_comm_init_rccl_impl(const april_graph_cholesky_param_t *param, 
 // callbacks), ncclCommCount, ncclCommUserRank, ncclGetVersion code, HIP device}; path (may be null) receives the librccl
 // file the symbols came from
 int shard_comm_info(const april_graph_cholesky_param_t *param, long long *out, char *path, int cap) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, nullptr);
     auto it = g_shard.find(param);
     if (it == g_shard.end()) return -1;
     ShardState &S = *it->second;
-    out[0] = 0; out[1] = S.world; out[2] = S.rank; out[3] = 0; out[4] = g_device;
+    out[0] = 0; out[1] = S.world; out[2] = S.rank; out[3] = 0; out[4] = physical_device(t_slot);
     if (path && cap > 0) path[0] = 0;
     if (!S.tr) return 0;
     if (auto *R = dynamic_cast<RcclTransport *>(S.tr.get())) {
@@ -331,7 +332,7 @@ int shard_comm_info(const april_graph_cholesky_param_t *param, long long *out, c
     return 0;
 }
 int shard_comm_init_host(const april_graph_cholesky_param_t *param, const aprilsam_amd_host_comm_t *cb) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, nullptr);
     auto it = g_shard.find(param);
     if (it == g_shard.end() || !cb || !cb->send || !cb->recv || !cb->bcast || !cb->allreduce_sum) return -1;
     auto T = std::make_unique<HostTransport>();
@@ -345,7 +346,7 @@ int shard_comm_init_host(const april_graph_cholesky_param_t *param, const aprils
 static int shard_iterate_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int n);
 int shard_iterate(april_graph_t *g, april_graph_cholesky_param_t *param, int n) { return guarded_rc(param, g, [&] { return shard_iterate_impl(g, param, n); }); }
 static int shard_iterate_impl(april_graph_t *g, april_graph_cholesky_param_t *param, int n) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, g);
     auto it = g_shard.find(param); auto ic = g_ctx.find(param);
     if (it == g_shard.end() || ic == g_ctx.end()) return -1;
     ShardState &S = *it->second; Context &c = *ic->second;
@@ -353,7 +354,7 @@ static int shard_iterate_impl(april_graph_t *g, april_graph_cholesky_param_t *pa
     GraphPack &gp = pack_for(g);
     const Plan &P = c.plan;
     hipStream_t s = gp.stream;
-    HIPCHECK(hipSetDevice(g_device));
+    
     set_small_attr();
     const int N = gp.N, me = S.rank;
     auto nop = [](int) {}; auto nop0 = []() {};
@@ -429,14 +430,14 @@ static int shard_iterate_impl(april_graph_t *g, april_graph_cholesky_param_t *pa
 static int shard_gather_states_impl(april_graph_t *g, april_graph_cholesky_param_t *param);
 int shard_gather_states(april_graph_t *g, april_graph_cholesky_param_t *param) { return guarded_rc(param, g, [&] { return shard_gather_states_impl(g, param); }); }
 static int shard_gather_states_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, g);
     auto it = g_shard.find(param); auto ic = g_ctx.find(param);
     if (it == g_shard.end() || ic == g_ctx.end()) return -1;
     ShardState &S = *it->second; Context &c = *ic->second;
     if (S.world > 1 && !S.tr) return -7;
     GraphPack &gp = pack_for(g);
     hipStream_t s = gp.stream;
-    HIPCHECK(hipSetDevice(g_device));
+    
     const int N = gp.N;
     if (S.tr) {
         S.d_scratch.need((size_t)9 * N);
@@ -474,13 +475,13 @@ double shard_chi2(april_graph_t *g, april_graph_cholesky_param_t *param) {
     return out;
 }
 static double shard_chi2_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, g);
     auto it = g_shard.find(param); auto ic = g_ctx.find(param);
     if (it == g_shard.end() || ic == g_ctx.end()) return -1;
     GraphPack &gp = pack_for(g);
     const Plan &P = ic->second->plan; ShardState &S = *it->second;
     hipStream_t s = gp.stream;
-    HIPCHECK(hipSetDevice(g_device));
+    
     hipLaunchKernelGGL(k_chi2, dim3((gp.F + TPB - 1) / TPB), dim3(TPB), 0, s, gp.F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p, gp.d_state.p, gp.d_chi2f.p);
     std::vector<double> h(gp.F);
     HIPCHECK(hipMemcpyAsync(h.data(), gp.d_chi2f.p, (size_t)8 * gp.F, hipMemcpyDeviceToHost, s));
@@ -498,7 +499,7 @@ static double shard_chi2_impl(april_graph_t *g, april_graph_cholesky_param_t *pa
     return acc;
 }
 void shard_end(const april_graph_cholesky_param_t *param) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    SlotLock lk(param, nullptr);
     auto it = g_shard.find(param);
     if (it != g_shard.end()) { it->second->release(); g_shard.erase(it); }
 }

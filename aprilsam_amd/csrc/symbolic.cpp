@@ -17,10 +17,15 @@
 #include <cstdlib>
 #include <tuple>
 #include <chrono>
+#include <mutex>
 
 namespace asam {
 
 void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf_nodes) {
+    // one plan at a time: the dissection and the symbolic phases share ONE pool of planner threads (ordering.cpp: PlanPool) -- calls
+    // from threads that drive different devices queue up here, everything else they do runs side by side
+    static std::mutex build_mu;
+    std::lock_guard<std::mutex> build_lock(build_mu);
     P = Plan();
     P.N = N; P.F = F; P.leaf_nodes = leaf_nodes;
     if (N <= 0) return;

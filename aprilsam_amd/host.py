@@ -79,6 +79,8 @@ class SolverLib:
             d.aprilsam_amd_resident_chi2.argtypes = [C.POINTER(abi.Graph)]
             d.aprilsam_amd_resident_chi2.restype = C.c_double
             d.aprilsam_amd_set_device.argtypes = [C.c_int]
+            d.aprilsam_amd_param_set_device.argtypes = [C.POINTER(abi.CholeskyParam), C.c_int]
+            d.aprilsam_amd_param_get_device.argtypes = [C.POINTER(abi.CholeskyParam)]
             d.aprilsam_amd_make_lattice.argtypes = [C.POINTER(abi.Graph), C.c_int]
             d.aprilsam_amd_lattice_arrays.argtypes = [C.c_int, _dp, _ip, _ip, _dp, _dp]
             d.aprilsam_amd_graph_from_arrays.argtypes = [C.POINTER(abi.Graph), C.c_int, _dp, C.c_int, _ip, _ip, _dp, _dp]

@@ -202,6 +202,16 @@ int aprilsam_amd_selftest(void);
 int aprilsam_amd_device_count(void);
 /* Select the HIP device used by contexts created afterwards (default: LOCAL_RANK env or 0). */
 int aprilsam_amd_set_device(int device);
+/* Bind ONE param (and the graph it is called with) to a device slot, 0 <= slot < 64: slot s runs on HIP device s % device_count, so on a
+ * node with N devices the slots 0 .. N-1 are the devices and further slots share them.  Calls on params bound to different slots run
+ * concurrently from different threads (each slot has its own lock, every call makes its slot's device current on the calling thread):
+ * one C process can drive N solves on N devices without forking -- the reference's solver has no process-wide state either (SURVEY
+ * section 8(b) "Threading").  Calls on the same slot are serialised.  Whatever the param held (plan, fronts, captured graphs) is dropped;
+ * a graph's device copies follow the slot of the param it is called with (one graph is driven from one slot at a time).  Options
+ * (aprilsam_amd_set_option) stay process-global: set them while no call is in flight.  Returns 0, -1 for a bad slot.
+ * aprilsam_amd_param_get_device: the HIP device a call on this param runs on. */
+int aprilsam_amd_param_set_device(const april_graph_cholesky_param_t *param, int slot);
+int aprilsam_amd_param_get_device(const april_graph_cholesky_param_t *param);
 
 /* Per-param solver statistics of the LAST solver call (all times in milliseconds).  */
 typedef struct aprilsam_amd_stats {

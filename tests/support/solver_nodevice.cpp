@@ -55,6 +55,8 @@ int selftest() { return -1; }                 // (the index arithmetic it checks
 void shard_map(const Plan &, int, std::vector<int> &, std::vector<char> &, std::vector<long long> &, std::vector<long long> &) {}
 std::vector<long long> shard_critical_path(const Plan &, int, const std::vector<int> &, const std::vector<char> &) { return {}; }
 int api_set_device(int) { return -1; }
+int api_param_set_device(const april_graph_cholesky_param_t *, int) { return -1; }
+int api_param_get_device(const april_graph_cholesky_param_t *) { return -1; }
 int api_set_option(const char *name, double v) {
     if (name && !strcmp(name, "leaf_nodes")) { g_opt.leaf_nodes = (int)v; return 0; }
     if (name && !strcmp(name, "pin_last")) { g_opt.pin_last = (int)v; return 0; }
