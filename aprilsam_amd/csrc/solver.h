@@ -25,6 +25,8 @@ struct Options {
     int speculate_factors = 1;    // warm batch calls: the pass over the factor objects (edits in place) runs under the GPU's work on the packed copies; an edit voids the run
     int syrk_xcd_order = 512;     // wide trailing updates of at least this many tiles (one round of workgroups is 512): tile order in which every XCD works on 8 x 8 blocks of tiles (kernels.hip.h: trapezoid_tile_xcd); 0 = never
     int syrk_small_tiles = 320;   // wide trailing updates of fewer 64 x 64 tiles than this (a quarter of a round of workgroups) use 32 x 32 tiles; 0 = never.  Measured on the 100 k lattice: k_syrk_big 0.664 (never) / 0.633 (320) / 0.648 (640) / 0.676 (1280) ms -- such a launch is 27 us of start / end latencies whatever its tiles
+    int syrk_pair_tiles = 2048;   // big fronts: levels whose first wide update has at least this many 64 x 64 tiles close every PAIR of outer blocks with one K = 256 update (after the first block of a pair only the next block's columns are updated); 0 = never.  Smaller updates are a launch's worth of latency whatever their K: pairs only add a launch there
+    int syrk_group = 3;           // ... outer blocks per group (2: pairs, K = 256; 3: K = 384 -- measured best on the 1 M lattice: k_syrk_big 14.9 -> 13.1 (2) -> 12.75 (3) -> 12.9 ms (4, 6); inside a group the next block's columns are updated left-looking with K = the group's blocks so far)
     int schur_first = 40;         // panel-mode small fronts with at least this many update blocks: update columns assembled after the Schur product has been stored into them (0 = never; M3500's fronts stay below: on its latency path the second assembly pass costs more than the zero fill it saves)
     int small_threads = 1024;     // workgroup size of k_front_small (256 / 512 / 1024) on latency-bound levels ...
     int tp_threads = 512;         // ... and on throughput levels (>= tp_fronts fronts)

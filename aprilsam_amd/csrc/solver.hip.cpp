@@ -60,7 +60,7 @@ static const OptionDef OPTION_TABLE[] = {
     { "leaf_nodes", &Options::leaf_nodes, 1, false }, { "deterministic", &Options::deterministic, 0, true }, { "use_graph", &Options::use_graph, 0, true },
     { "device_timing", &Options::device_timing, 0, true }, { "trust_factor_cache", &Options::trust_factor_cache, 0, true },
     { "small_lds_kb", &Options::small_lds_kb, 0, false }, { "syrk_xcd_order", &Options::syrk_xcd_order, 0, false },
-    { "schur_first", &Options::schur_first, 0, false }, { "syrk_small_tiles", &Options::syrk_small_tiles, 0, false }, { "panel_mode", &Options::panel_mode, 0, false },
+    { "schur_first", &Options::schur_first, 0, false }, { "syrk_small_tiles", &Options::syrk_small_tiles, 0, false }, { "syrk_pair_tiles", &Options::syrk_pair_tiles, 0, false }, { "syrk_group", &Options::syrk_group, 2, false }, { "panel_mode", &Options::panel_mode, 0, false },
     { "small_threads", &Options::small_threads, 64, false }, { "tp_fronts", &Options::tp_fronts, 0, false }, { "tp_lds_kb", &Options::tp_lds_kb, 0, false },
     { "tp_threads", &Options::tp_threads, 64, false }, { "inc_fast", &Options::inc_fast, 0, true }, { "inc_multi", &Options::inc_multi, 0, true },
     { "inc_one", &Options::inc_one, 0, true }, { "inc_one_up", &Options::inc_one_up, 1, true }, { "inc_one_dn", &Options::inc_one_dn, 1, true },
@@ -234,9 +234,9 @@ int selftest() {
         std::vector<int> applied((size_t)Rv * C, 0);          // number of K columns applied to (i, j), j < C, i < Rv
         std::vector<long long> ksum((size_t)Rv * C, 0);       // sum of applied k (detects duplicates / wrong columns)
         const int steps = (ns + NB - 1) / NB;
-        auto run = [&](int s_lo, int s_hi, int tile) -> int {
-            const SyrkRange g = syrk_range(R, C, ns, s_lo, s_hi, tile);
-            const int nt = syrk_tiles(R, C, ns, s_lo, s_hi, tile);
+        auto run = [&](int s_lo, int s_hi, int tile, bool ahead = false) -> int {
+            const SyrkRange g = syrk_range(R, C, ns, s_lo, s_hi, tile, ahead);
+            const int nt = syrk_tiles(R, C, ns, s_lo, s_hi, tile, ahead);
             if (nt != g.ntc * g.ntr - g.ntc * (g.ntc - 1) / 2) return -11;
             std::vector<char> seen((size_t)std::max(1, g.ntr) * std::max(1, g.ntc), 0);
             for (int l = 0; l < nt; l++) {
@@ -264,6 +264,24 @@ int selftest() {
             for (int j = ns; j < C; j++)
                 for (int i = j; i < Rv; i++)
                     if (applied[(size_t)j * Rv + i] != ns || ksum[(size_t)j * Rv + i] != (long long)ns * (ns - 1) / 2) return -14;
+        }
+        for (int G : { 2, 3, 4 }) for (int tile : { TILE, TILE / 2 }) {          // ... and the same with GROUPS of outer blocks (options syrk_pair_tiles, syrk_group)
+            std::fill(applied.begin(), applied.end(), 0); std::fill(ksum.begin(), ksum.end(), 0);
+            const int nobs = (steps + OBP - 1) / OBP;
+            for (int o = 0; o < nobs; o++) {
+                const int k0 = o * OBP * NB, k1 = std::min(ns, k0 + OBP * NB);
+                for (int j = k0; j < k1; j++)
+                    for (int i = j; i < Rv; i++)
+                        if (applied[(size_t)j * Rv + i] != k0 || ksum[(size_t)j * Rv + i] != (long long)k0 * (k0 - 1) / 2) return -15;
+                int rc;
+                const int g0 = (o - o % G) * OBP;
+                if (o % G != G - 1) rc = run(g0, (o + 1) * OBP, tile, o + 1 < nobs);          // inside a group: the next block's columns only, K = the group so far (a front's last block: wide)
+                else rc = run(g0, (o + 1) * OBP, tile);                                       // last of a group: everything to the right, K = the whole group
+                if (rc) return rc;
+            }
+            for (int j = ns; j < C; j++)
+                for (int i = j; i < Rv; i++)
+                    if (applied[(size_t)j * Rv + i] != ns || ksum[(size_t)j * Rv + i] != (long long)ns * (ns - 1) / 2) return -16;
         }
         // (2) packed Schur update: offsets are the running count of (rows from the top of the diagonal block to the rhs row)
         long long run_off = 0;

@@ -13,6 +13,8 @@ struct LevelPlan {
     int small_nt = 512;                                        // ... with this many threads per workgroup
     int n_big = 0; size_t asm_lds = 0;
     Launch asm_big{};                                          // k_assemble_big (chunks of block columns)
+    std::vector<Launch> syrka, syrk1;                          // paired outer blocks (option syrk_pair_tiles; empty: every block closes with syrkw): after the FIRST block of a pair the "ahead" update of the fronts that have a second one, and the single-block wide update of the fronts that end here; syrkw then holds the K = 256 update after the second block
+    bool paired = false;
     std::vector<Launch> bchain, btile, syrkw;                  // per 128-column outer block: diagonal-block workgroups, row tiles (Launch::tile = rows per wave / 16), the wide update that closes it (Launch::tile = output tile)
     int all_off = 0, n_all = 0; size_t solve_lds = 0;          // every front (k_backsolve)
     size_t solve_w_lds = 0; int maxns = 0;                     // ... in the column-per-lane form (k_backsolve_w: L panel in LDS), widest own part
@@ -353,17 +355,54 @@ static void build_level(LevelPlan &L, std::vector<int> &fronts, std::vector<int>
     }
     const int steps = (3 * nsb_of(big[0]) + NB - 1) / NB;
     auto active = [&](int sidx) { int nact = 0; while (nact < (int)big.size() && 3 * nsb_of(big[nact]) > sidx * NB) nact++; return nact; };
-    // the wide update that closes every outer block of OBP panels (K = the block's columns, everything to its right)
-    for (int o = 0; o * OBP < steps; o++) {
-        const int s_lo = o * OBP, s_hi = std::min(s_lo + OBP, steps), nact = active(s_lo);
+    // the wide update that closes every outer block of OBP panels (K = the block's columns, everything to its right) -- or, on levels
+    // whose wide updates are large (option syrk_pair_tiles), every PAIR of outer blocks (syrk_range)
+    const int nobs = (steps + OBP - 1) / OBP;
+    auto make_sub = [&](int i0, int i1, auto count) {          // like make() for the fronts big[i0 .. i1)
+        Launch La; La.list_off = list_off + i0; La.n = i1 - i0; La.pre_off = (int)tab.size();
+        int acc = 0; tab.push_back(0);
+        for (int i = i0; i < i1; i++) { acc += count(big[i]); tab.push_back(acc); }
+        La.grid = acc; La.single = acc == La.n;
+        return La;
+    };
+    auto tile_for = [&](int i0, int i1, int s_lo, int s_hi, bool ahead) {
         int tile = TILE;
         if (g_opt.syrk_small_tiles > 0) {         // few tiles: 32 x 32 ones (k_syrk_big32)
             long long nt64 = 0;
-            for (int i = 0; i < nact; i++) nt64 += syrk_tiles(rows(big[i]), cols(big[i]), 3 * nsb_of(big[i]), s_lo, s_hi, TILE);
+            for (int i = i0; i < i1; i++) nt64 += syrk_tiles(rows(big[i]), cols(big[i]), 3 * nsb_of(big[i]), s_lo, s_hi, TILE, ahead);
             if (nt64 < g_opt.syrk_small_tiles) tile = TILE / 2;
         }
-        L.syrkw.push_back(make(nact, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, s_hi, tile); }));
-        L.syrkw.back().tile = tile;
+        return tile;
+    };
+    {
+        long long nt0 = 0;
+        for (int i = 0; i < active(0); i++) nt0 += syrk_tiles(rows(big[i]), cols(big[i]), 3 * nsb_of(big[i]), 0, OBP, TILE);
+        L.paired = g_opt.syrk_pair_tiles > 0 && nobs >= 2 && nt0 >= g_opt.syrk_pair_tiles;
+    }
+    for (int o = 0; o < nobs; o++) {
+        const int s_lo = o * OBP, s_hi = std::min(s_lo + OBP, steps), nact = active(s_lo);
+        if (!L.paired) {
+            const int tile = tile_for(0, nact, s_lo, s_hi, false);
+            L.syrkw.push_back(make(nact, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), s_lo, s_hi, tile); }));
+            L.syrkw.back().tile = tile;
+            continue;
+        }
+        const int G = std::max(2, g_opt.syrk_group), p_lo = (o - o % G) * OBP;       // K = the blocks of the group so far
+        if (o % G != G - 1) {
+            // not the last block of its group: fronts with a next block (a prefix of `big`, sorted by own columns) update that block's
+            // columns only; fronts whose last block this is get their wide update now
+            const int n2 = o + 1 < nobs ? active((o + 1) * OBP) : 0;
+            int tile = tile_for(0, n2, p_lo, s_hi, true);
+            L.syrka.push_back(make_sub(0, n2, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), p_lo, s_hi, tile, true); })); L.syrka.back().tile = tile;
+            tile = tile_for(n2, nact, p_lo, s_hi, false);
+            L.syrk1.push_back(make_sub(n2, nact, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), p_lo, s_hi, tile); })); L.syrk1.back().tile = tile;
+            L.syrkw.push_back(Launch{ 0, 0, 0, 0, false });
+        } else {
+            const int tile = tile_for(0, nact, p_lo, s_hi, false);
+            L.syrka.push_back(Launch{ 0, 0, 0, 0, false }); L.syrk1.push_back(Launch{ 0, 0, 0, 0, false });
+            L.syrkw.push_back(make(nact, [&](int t) { return syrk_tiles(rows(t), cols(t), 3 * nsb_of(t), p_lo, s_hi, tile); }));
+            L.syrkw.back().tile = tile;
+        }
     }
     // outer-block panels (kernels.hip.h: k_block_chain / k_block_solve): per 128-column outer block the active fronts (a
     // prefix of `big`, sorted by own columns) and their row tiles below the diagonal block
@@ -634,13 +673,18 @@ static void enqueue_big_steps(Context &c, const LevelPlan &L, hipStream_t s, Tic
             else hipLaunchKernelGGL(k_block_solve<1>, dim3(bt.grid), dim3(TPB), block_solve_lds(), s, c.dp, tab + bt.list_off, tab + bt.pre_off, bt.n, (int)o, c.d_pool.p, c.d_diag.p, c.d_dinv.p);
         }
         toc();
-        if (sw.grid > 0) {
+        auto wide = [&](const Launch &w, int s_lo, int s_hi, int mode) {
+            if (w.grid <= 0) return;
             tic(K_SYRK_BIG);
             // (s_lo, s_hi) in panel steps: the kernel clips s_hi * NB to the front's own columns
-            if (sw.tile == TILE / 2) hipLaunchKernelGGL(k_syrk_big32, dim3(sw.grid), dim3(TPB), 0, s, c.dp, tab + sw.list_off, tab + sw.pre_off, sw.n, (int)o * OBP, (int)(o + 1) * OBP, 1 | xcd, c.d_pool.p);
-            else hipLaunchKernelGGL(k_syrk_big, dim3(sw.grid), dim3(TPB), 0, s, c.dp, tab + sw.list_off, tab + sw.pre_off, sw.n, (int)o * OBP, (int)(o + 1) * OBP, 1 | xcd, c.d_pool.p);
+            if (w.tile == TILE / 2) hipLaunchKernelGGL(k_syrk_big32, dim3(w.grid), dim3(TPB), 0, s, c.dp, tab + w.list_off, tab + w.pre_off, w.n, s_lo, s_hi, mode | xcd, c.d_pool.p);
+            else hipLaunchKernelGGL(k_syrk_big, dim3(w.grid), dim3(TPB), 0, s, c.dp, tab + w.list_off, tab + w.pre_off, w.n, s_lo, s_hi, mode | xcd, c.d_pool.p);
             toc();
-        }
+        };
+        const int G = std::max(2, g_opt.syrk_group), g0 = (int)(o - o % G) * OBP;
+        if (!L.paired) wide(sw, (int)o * OBP, (int)(o + 1) * OBP, 1);
+        else if ((int)(o % G) != G - 1) { wide(L.syrka[o], g0, (int)(o + 1) * OBP, 2); wide(L.syrk1[o], g0, (int)(o + 1) * OBP, 1); }
+        else wide(sw, g0, (int)(o + 1) * OBP, 1);
     }
 }
 

@@ -537,6 +537,8 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         const int sh = (int)I.tab_used;
         L.all_off += sh; L.small_off += sh; L.asm_big.list_off += sh; L.asm_big.pre_off += sh;
         for (auto &x : L.syrkw) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.syrka) { x.list_off += sh; x.pre_off += sh; }
+        for (auto &x : L.syrk1) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.bchain) { x.list_off += sh; x.pre_off += sh; }
         for (auto &x : L.btile) { x.list_off += sh; x.pre_off += sh; }
         L.bs_blk.list_off += sh; L.bs_blk.pre_off += sh; L.rest_off += sh;

@@ -287,6 +287,10 @@ void aprilsam_amd_clear_error(void);
  *                       for the product); default 40, 0 = never
  *   "syrk_small_tiles"  wide trailing updates of fewer 64x64 tiles than this use 32x32 tiles (four times the workgroups, a quarter of
  *                       the K loop each); default 320 = a quarter of a round of workgroups, 0 = never
+ *   "syrk_pair_tiles", "syrk_group"  multi-workgroup fronts on levels whose first wide update has at least syrk_pair_tiles 64x64 tiles
+ *                       (default 2048; 0 = never) close every GROUP of syrk_group outer blocks (default 3; 2 .. 8) with ONE wide update of
+ *                       K = the group's columns instead of one per 128 columns: the far part of the trailing matrix is read and written once
+ *                       per group; inside a group only the next block's own columns are updated (left-looking, K = the group so far)
  *   "syrk_xcd_order"    wide trailing updates of at least this many 64x64 tiles use the XCD-aware tile order (default 512 = one
  *                       round of workgroups; 0 = never, 1 = always)
  *   "batch_extend"      1 (default): april_graph_cholesky on a graph that only GREW since the last plan keeps the plan -- the

@@ -84,6 +84,8 @@ def test_tutorial_batch_mode_matches_reference_golden(lib):
                                   dict(schur_first=1), dict(schur_first=1, small_lds_kb=48), dict(schur_first=1, persist=0, use_graph=0), dict(schur_first=8, leaf_nodes=40), dict(schur_first=0),
                                   dict(syrk_small_tiles=0, small_lds_kb=0), dict(syrk_small_tiles=1 << 30, small_lds_kb=0), dict(syrk_small_tiles=1 << 30, small_lds_kb=0, syrk_xcd_order=1),
                                   dict(syrk_xcd_order=1, small_lds_kb=0), dict(syrk_xcd_order=0, small_lds_kb=0),
+                                  dict(syrk_pair_tiles=1, syrk_group=2, small_lds_kb=0), dict(syrk_pair_tiles=1, syrk_group=3, small_lds_kb=0), dict(syrk_pair_tiles=1, syrk_group=4, small_lds_kb=0, syrk_small_tiles=0),
+                                  dict(syrk_pair_tiles=1, syrk_group=3, small_lds_kb=48, use_graph=0), dict(syrk_pair_tiles=0, small_lds_kb=0),
                                   dict(blk_backsolve=0, small_lds_kb=0), dict(blk_backsolve=0, small_lds_kb=48), dict(small_lds_kb=0, leaf_nodes=64), dict(small_lds_kb=0, leaf_nodes=4, use_graph=0),
                                   dict(leaf_nodes=4), dict(leaf_nodes=40), dict(use_graph=0), dict(device_timing=1), dict(pin_last=12), dict(trust_factor_cache=1),
                                   dict(linearize_staged_min=0), dict(persist=0), dict(persist_max_fronts=100000), dict(wave_backsolve=0), dict(wave_backsolve=0, persist=0)])

@@ -11,7 +11,7 @@ import tests.test_gpu_parity as T
 from tests.support import sweeps
 
 pytestmark = pytest.mark.gpu
-BIG = (dict(), dict(small_lds_kb=0), dict(small_lds_kb=0, blk_backsolve=0))
+BIG = (dict(), dict(small_lds_kb=0), dict(small_lds_kb=0, blk_backsolve=0), dict(small_lds_kb=0, syrk_pair_tiles=1))
 
 
 @pytest.mark.parametrize("guard", [0, 512])
@@ -42,7 +42,8 @@ def test_structured_graphs(lib, oracle):
 
 def test_odd_lattices(lib, oracle):
     sweeps.sweep_batch(lib, oracle, [(f"lattice K={K}", lib.lattice_arrays(K)) for K in (37, 91)],
-                       (dict(), dict(small_lds_kb=0), dict(small_lds_kb=48, leaf_nodes=24), dict(small_lds_kb=0, leaf_nodes=7, syrk_xcd_order=1, syrk_small_tiles=1 << 30)),
+                       (dict(), dict(small_lds_kb=0), dict(small_lds_kb=48, leaf_nodes=24), dict(small_lds_kb=0, leaf_nodes=7, syrk_xcd_order=1, syrk_small_tiles=1 << 30),
+                        dict(small_lds_kb=0, syrk_pair_tiles=1, syrk_group=2), dict(small_lds_kb=0, syrk_pair_tiles=1, syrk_group=4)),
                        1e-8, 1e-6, log=lambda s: None)
 
 
