@@ -709,7 +709,7 @@ static void enqueue_factor_level(Context &c, const LevelPlan &L, hipStream_t s, 
 // enqueue: linearise -> per level {assemble+factor} -> back substitution -> state update
 // ev != null: record stage events (0 start, 1 after linearise, 2 after factor, 3 after solve+update)
 // ktime: bracket EVERY kernel launch with its own HIP event pair on this stream (c.k_ev / c.k_ids)
-static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t *ev, bool unary_at_lp = false, bool ktime = false, bool io_host = false) {
+static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t *ev, bool unary_at_lp = false, bool ktime = false, bool io_host = false, bool relin = false) {
     const Plan &P = c.plan;
     const int F = P.F, N = P.N;
     size_t nev = 0;
@@ -749,7 +749,7 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     if (ev) HIPCHECK(hipEventRecord(ev[2], s));
     // the state update of a front's own poses rides on its back substitution (no kernel of its own); the last launch also
     // mirrors the pivot flag for the API call
-    UpdArgs upd{ c.d_perm.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p, io_host ? gp.h_lp.p : nullptr, io_host ? gp.h_dx.p : nullptr, nullptr };
+    UpdArgs upd{ c.d_perm.p, gp.d_lp.p, gp.d_state.p, gp.d_dx.p, io_host ? gp.h_lp.p : nullptr, io_host ? gp.h_dx.p : nullptr, nullptr, relin ? gp.d_lp.p : nullptr };
     if (l0 < P.nLevels) {
         UpdArgs u = upd; if (l0 == 0) u.bad_out = io_host ? c.h_bad.p : nullptr;
         tic(K_BACKSOLVE);
@@ -783,7 +783,7 @@ static void collect_kernel_times(Context &c) {
 }
 
 // run the numeric phase, replaying a captured hipGraph when enabled
-static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp = false, bool io_host = false) {
+static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp = false, bool io_host = false, bool relin = false) {
     hipStream_t s = gp.stream;
     set_small_attr();
     if (timing && !c.have_events) { for (auto &e : c.ev) HIPCHECK(hipEventCreate(&e)); c.have_events = true; }
@@ -814,7 +814,7 @@ static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp
             c.retire(c.gexec);
             hipGraph_t graph = nullptr;
             HIPCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            enqueue_numeric(c, gp, s, nullptr);
+            enqueue_numeric(c, gp, s, nullptr, false, false, false, relin);
             HIPCHECK(hipStreamEndCapture(s, &graph));
             HIPCHECK(hipGraphInstantiate(&c.gexec, graph, nullptr, nullptr, 0));
             HIPCHECK(hipGraphDestroy(graph));
@@ -823,7 +823,7 @@ static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp
         c.graph_stream = s;
         HIPCHECK(hipGraphLaunch(c.gexec, s));
     } else {
-        enqueue_numeric(c, gp, s, timing ? c.ev : nullptr, unary_at_lp);
+        enqueue_numeric(c, gp, s, timing ? c.ev : nullptr, unary_at_lp, false, false, relin);
     }
 }
 
