@@ -3,8 +3,8 @@
 // ------------------------------------------------------------------------------------------------------
 // solver context — one per april_graph_cholesky_param_t pointer
 // ------------------------------------------------------------------------------------------------------
-enum { K_LINEARIZE = 0, K_FRONT_SMALL, K_ASSEMBLE_BIG, K_DIAG_BIG, K_PANEL_BIG, K_SYRK_BIG, K_BACKSOLVE, K_UPDATE, NKERN };
-static const char *const KNAMES[NKERN] = { "k_linearize", "k_front_small", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big", "k_backsolve", "k_update_states" };
+enum { K_LINEARIZE = 0, K_FRONT_SMALL, K_ASSEMBLE_BIG, K_PANEL_BIG, K_SYRK_BIG, K_BACKSOLVE, K_UPDATE, NKERN };      // K_PANEL_BIG = k_block_chain + k_block_solve, K_SYRK_BIG = k_syrk_big + k_syrk_big32, K_BACKSOLVE = every back-substitution kernel
+static const char *const KNAMES[NKERN] = { "k_linearize", "k_front_small", "k_assemble_big", "k_panel_big", "k_syrk_big", "k_backsolve", "k_update_states" };
 struct Launch { int list_off, pre_off, n, grid; bool single = false; int tile = TILE; };   // single: every front has exactly one work item     // offsets into the int launch-table buffer
 
 struct LevelPlan {

@@ -44,7 +44,8 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak; HBM peak from MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 PMC_TAG = "r05"              # profiles/<tag>_pmc_*.json written by tools/profile_round.sh <tag>
-FLOP_KERNELS = {"k_front_small", "k_front_medium", "k_syrk_big", "k_panel_big", "k_diag_big"}
+FLOP_KERNELS = {"k_front_small", "k_syrk_big", "k_panel_big"}
+FACTOR_KERNELS = ("k_front_small", "k_assemble_big", "k_panel_big", "k_syrk_big")      # profile slots of the factorisation (k_panel_big = k_block_chain + k_block_solve)
 
 
 def kernel_profile(lib, p):
@@ -95,8 +96,8 @@ def pmc_traffic(pmc, kernel):
 
 
 # rocprofv3 kernel names of the K_BACKSOLVE / K_PANEL_BIG slots (several kernels share a slot)
-PMC_NAMES = {"k_linearize": ("k_linearize_t",), "k_backsolve": ("k_backsolve_blk", "k_backsolve_t", "k_backsolve_w", "k_backsolve_gemv"), "k_panel_big": ("k_block_chain", "k_block_solve", "k_diagpanel_ll"),
-             "k_syrk_big": ("k_syrk_big", "k_syrk_big32", "k_syrk_big_w2", "k_syrk_big128")}
+PMC_NAMES = {"k_linearize": ("k_linearize_t",), "k_backsolve": ("k_backsolve_blk", "k_backsolve_t", "k_backsolve_w", "k_backsolve_gemv"), "k_panel_big": ("k_block_chain", "k_block_solve"),
+             "k_syrk_big": ("k_syrk_big", "k_syrk_big32")}
 
 
 def hbm_rooflines(prof, iters, pmc_file=None, survey_bytes=None):
@@ -323,7 +324,7 @@ def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iter
         lib.dll.aprilsam_amd_resident_steps(g.ptr, p.ptr, 2, 1)
         lp = kernel_profile(lib, p); st = p.stats()
         levels = level_profile(lib, p, 2)
-        fac_ms = sum(k["ms"] / 2 for k in lp if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big"))
+        fac_ms = sum(k["ms"] / 2 for k in lp if k["name"] in FACTOR_KERNELS)
         lev_ms = sum(L["factor_ms"] + L["backsolve_ms"] for L in levels)
         all_ms = sum(k["ms"] / 2 for k in lp)
         res["level_times"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in L.items()} for L in levels]
@@ -567,7 +568,7 @@ def main():
                 launches_per_step=dom["launches_per_iter"], kernel_ms_per_step=dom["ms_per_iter"],
                 algorithmic_work_per_step=dom["flops"] if dom["name"] in FLOP_KERNELS else dom["bytes"],
                 measured="HIP events around every launch of this kernel on the solver stream, instrumented pass of the same K steps")
-    factorise_ms = sum(k["ms_per_iter"] for k in prof if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big"))
+    factorise_ms = sum(k["ms_per_iter"] for k in prof if k["name"] in FACTOR_KERNELS)
 
     out = {
         "metric": "Gauss-Newton iterations/sec + factorise ms on M3500 (chi2 match <=1e-6)",
@@ -620,7 +621,7 @@ def main():
                 "reference_cpu_s_per_iter_survey_container": 44.8,
                 "nnz_L": ls["nnz_L"], "sum_cj2": ls["flops_factor"], "fronts": ls["n_fronts"], "levels": ls["n_levels"],
                 "kernels_ms_per_step": {k["name"]: round(k["ms"] / 3, 4) for k in lp},
-                "factor_tflops": ls["flops_factor"] / (1e-3 * sum(k["ms"] / 3 for k in lp if k["name"] in ("k_front_small", "k_front_medium", "k_assemble_big", "k_diag_big", "k_panel_big", "k_syrk_big"))) / 1e12,
+                "factor_tflops": ls["flops_factor"] / (1e-3 * sum(k["ms"] / 3 for k in lp if k["name"] in FACTOR_KERNELS)) / 1e12,
                 "roofline": big_front_rooflines(lp, 3, PMC_TAG + "_pmc_mfma.json"),
                 "roofline_hbm": hbm_rooflines(lp, 3, PMC_TAG + "_pmc_hbm_lattice100k.json", survey_assembly_bytes(316 * 316, len(arr[1]) - 1, 1)),
             }

@@ -4,7 +4,7 @@
 # Outputs under gpurun_out/prof_<tag>/ ; tools/pmc_aggregate.py turns them into the files kept in profiles/.
 # Counter passes are separate runs (one --pmc set each, no trace domains besides the kernel trace), without hipGraph
 # replay (counter collection over graph replays does not terminate on ROCm 7.2) and each under its own timeout.
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
