@@ -104,11 +104,15 @@ static int g_device = -1;                         // the process default slot
 static std::mutex g_slot_mu[MAX_SLOTS];
 static thread_local int t_slot = 0;               // slot of the call in progress on this thread
 static int device_count() {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    static std::atomic<int> cached{ 0 };               // (a positive count does not change during the life of the process; zero is asked again)
+    int n = cached.load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (n > 0) cached.store(n, std::memory_order_relaxed);
     return n;
 }
 static int physical_device(int slot) { const int n = device_count(); return n > 0 ? slot % n : 0; }
+static thread_local int t_device = -1;             // the device this thread last made current through a SlotLock (hipSetDevice costs microseconds: 3 500 incremental steps feel it)
 template <class V> struct Registry {             // std::map: iterators and elements stay put when OTHER keys come and go
     using Map = std::map<const void *, std::unique_ptr<V>>;
     Map m; mutable std::mutex mu;
@@ -120,16 +124,25 @@ template <class V> struct Registry {             // std::map: iterators and elem
     template <class F> void for_each(F &&f) { std::lock_guard<std::mutex> lk(mu); for (auto &kv : m) f(*kv.second); }
 };
 static std::map<const void *, int> g_param_slot; static std::mutex g_param_slot_mu;      // aprilsam_amd_param_set_device
+static std::atomic<int> g_param_slot_n{ 0 };      // bound params (zero: every call takes the default slot without looking)
 static int default_slot() { return g_device < 0 ? 0 : g_device % MAX_SLOTS; }
 static int slot_of_graph(const void *g);          // solver_pack.inc.h: the slot its pack lives on, or -1
 static int slot_for(const void *param, const void *g) {
-    if (param) { std::lock_guard<std::mutex> lk(g_param_slot_mu); auto it = g_param_slot.find(param); if (it != g_param_slot.end()) return it->second; }
+    if (param && g_param_slot_n.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(g_param_slot_mu); auto it = g_param_slot.find(param); if (it != g_param_slot.end()) return it->second; }
     if (!param && g) { const int s = slot_of_graph(g); if (s >= 0) return s; }
     return default_slot();
 }
 struct SlotLock {
     int slot; std::unique_lock<std::mutex> lk;
-    SlotLock(const void *param, const void *g) : slot(slot_for(param, g)), lk(g_slot_mu[slot]) { t_slot = slot; if (device_count() > 0) (void)hipSetDevice(physical_device(slot)); }
+    SlotLock(const void *param, const void *g) : slot(slot_for(param, g)), lk(g_slot_mu[slot]) {
+        t_slot = slot;
+        if (device_count() > 0) {
+            const int dev = physical_device(slot);
+            int cur = -1;
+            // (the caller may have changed this thread's device behind our back: ask, which is cheap; set only when it differs)
+            if (t_device != dev || hipGetDevice(&cur) != hipSuccess || cur != dev) { (void)hipSetDevice(dev); t_device = dev; }
+        }
+    }
 };
 static std::once_flag g_dev_once;
 static void ensure_device() {
@@ -329,6 +342,7 @@ int api_param_set_device(const april_graph_cholesky_param_t *param, int slot) {
     drop_context(param);                            // (under the lock of the slot it was on)
     std::lock_guard<std::mutex> lk(g_param_slot_mu);
     g_param_slot[param] = slot;
+    g_param_slot_n.store((int)g_param_slot.size(), std::memory_order_release);
     return 0;
 }
 int api_param_get_device(const april_graph_cholesky_param_t *param) { return physical_device(slot_for(param, nullptr)); }

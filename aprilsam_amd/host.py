@@ -68,8 +68,9 @@ class SolverLib:
             d.aprilsam_amd_version.restype = C.c_char_p
             d.aprilsam_amd_get_stats.argtypes = [C.POINTER(abi.CholeskyParam), C.POINTER(abi.Stats)]
             d.aprilsam_amd_set_option.argtypes = [C.c_char_p, C.c_double]
-            d.aprilsam_amd_get_option.argtypes = [C.c_char_p, _dp]
-            d.aprilsam_amd_debug_guard_selftest.argtypes = [C.POINTER(abi.CholeskyParam)]
+            if hasattr(d, "aprilsam_amd_get_option"):          # (absent from builds of earlier rounds, which tools/ A/B against this one)
+                d.aprilsam_amd_get_option.argtypes = [C.c_char_p, _dp]
+                d.aprilsam_amd_debug_guard_selftest.argtypes = [C.POINTER(abi.CholeskyParam)]
             d.aprilsam_amd_last_error.argtypes = [C.c_char_p, C.c_int]
             d.aprilsam_amd_batch_resident.argtypes = [C.POINTER(abi.Graph), C.POINTER(abi.CholeskyParam),
                                                       C.c_int, _dp, _dp]
@@ -79,8 +80,9 @@ class SolverLib:
             d.aprilsam_amd_resident_chi2.argtypes = [C.POINTER(abi.Graph)]
             d.aprilsam_amd_resident_chi2.restype = C.c_double
             d.aprilsam_amd_set_device.argtypes = [C.c_int]
-            d.aprilsam_amd_param_set_device.argtypes = [C.POINTER(abi.CholeskyParam), C.c_int]
-            d.aprilsam_amd_param_get_device.argtypes = [C.POINTER(abi.CholeskyParam)]
+            if hasattr(d, "aprilsam_amd_param_set_device"):
+                d.aprilsam_amd_param_set_device.argtypes = [C.POINTER(abi.CholeskyParam), C.c_int]
+                d.aprilsam_amd_param_get_device.argtypes = [C.POINTER(abi.CholeskyParam)]
             d.aprilsam_amd_make_lattice.argtypes = [C.POINTER(abi.Graph), C.c_int]
             d.aprilsam_amd_lattice_arrays.argtypes = [C.c_int, _dp, _ip, _ip, _dp, _dp]
             d.aprilsam_amd_graph_from_arrays.argtypes = [C.POINTER(abi.Graph), C.c_int, _dp, C.c_int, _ip, _ip, _dp, _dp]

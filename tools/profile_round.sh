@@ -31,8 +31,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 # phase stamps of the outer-block chain kernel (root front of the 100k lattice)
 timeout 120 python $ROOT/tools/chain_times.py 316 > $OUT/chain_times_lattice100k.txt 2>&1
-# the reference CPU on the 100k lattice on THIS host: one april_graph_cholesky call (about a minute, one core)
-timeout 400 python $ROOT/bench.py --steps 20 --warmup 3 --no-inc --no-cpu-baseline --lattice1m-k 0 --cpu-lattice100k > $OUT/bench_cpu_lattice100k.json 2> $OUT/bench_cpu_lattice100k.err
 # config 3: the incremental demo (first 1500 poses)
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_inc -- python $ROOT/tools/inc_demo.py 3500 > $OUT/stats_inc.log 2>&1
 python $ROOT/tools/trace_medians.py $OUT/stats_inc > $OUT/inc_trace_medians.txt 2>&1
