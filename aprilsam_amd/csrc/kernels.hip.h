@@ -10,10 +10,13 @@
 //                      workgroup (replaces cs_chol csparse.c:462-512); per-level launches, or ONE launch over
 //                      several levels with per-front dependency flags                          latency bound
 //   k_assemble_big     chunked gather-assembly of large fronts in HBM (L2 atomics as fire-and-forget adds)
-//   k_diagpanel_ll     NB-wide panel step of the large fronts, left-looking inside an outer block: earlier panels'
-//                      updates (MFMA), diagonal block on one wave (v_readlane chain), row solves -- one launch
-//   k_diagpanel_multi / k_diagpanel_big / k_diag_big / k_panel_big   the right-looking forms (options)
-//   k_syrk_big         trailing update C -= P P^T with v_mfma_f64_16x16x4_f64, outer-blocked   FP64-MFMA bound
+//   k_block_chain      the 128 x 128 diagonal block of an outer block of a large front: four 32-column pivot chains on one wave
+//                      (v_readlane), the inverses of the 32 x 32 diagonal blocks as a by-product, rows below solved and updated by six
+//                      more waves on the matrix cores -- one workgroup per front                            latency bound
+//   k_block_solve      the rows below that block: Y = X L11^-T panel by panel on the matrix cores, in registers
+//   k_syrk_big(32)     trailing update C -= P P^T with v_mfma_f64_16x16x4_f64, once per outer block or per GROUP of outer blocks
+//                      (K = 128 .. 384; 64 x 64 or 32 x 32 tiles)                                          FP64-MFMA bound
+//   k_backsolve_blk    back substitution of the wide fronts, 128 columns at a time: a chain workgroup + helpers, flags
 //   k_backsolve_w      x_T = L11^-T (y_T - L21^T x_struct) for fronts whose L panel fits LDS: a lane owns a column,
 //                      one in-register chain per 64 columns (smatd.c:1075); multi-level or per-level launches
 //   k_backsolve_gemv / k_backsolve_t   the same for all other fronts, 32 columns at a time, level by level
@@ -22,6 +25,9 @@
 //   k_chi2 / k_reduce  chi^2 with the 1/2-on-xyt convention (april_graph.c:79-98), deterministic sum
 //   k_scatter_host     blocks of host-evaluated (foreign-type) factors into the contribution slots
 //   k_pack_update      packed Schur update of a front for the multi-GPU exchange
+//   k_inc_prologue / k_inc_one / front_update_body   the incremental path: patches + linearisation of the new factors, a whole small
+//                      step in one workgroup, low-rank updates of the fronts on a loop closure's root path
+//   k_guard            debug option pool_guard: NaN-filled guard bands behind every frontal array
 //
 // The forward solve U^T y = B (smatd.c:1051) has no kernel of its own: the right-hand side rides along
 // as an extra ROW of every front, so the factorisation leaves y in place.
