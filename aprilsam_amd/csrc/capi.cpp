@@ -25,7 +25,8 @@ void APRILSAM_VERSION(void) {
 
 // replaces aprilsam.c:45-64
 void april_graph_cholesky_param_init(april_graph_cholesky_param_t *param) {
-    asam::drop_context(param);                 // a re-initialised param starts with no solver state
+    asam::drop_context(param);                 // a re-initialised param starts with no solver state ...
+    asam::unbind_param(param);                 // ... on the default device slot
     memset(param, 0, sizeof(*param));
     param->tikhanov = 0.0001;
     param->nreordering = 1;
@@ -35,6 +36,7 @@ void april_graph_cholesky_param_init(april_graph_cholesky_param_t *param) {
 void april_graph_cholesky_param_destory(april_graph_cholesky_param_t *param) {
     if (!param) return;
     asam::drop_context(param);
+    asam::unbind_param(param);
     free(param->delta_x); free(param->B); free(param->y); free(param->ordering);
     // chol / A / tr are never set by this library (reference-owned CPU state)
     free(param);

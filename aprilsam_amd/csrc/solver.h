@@ -83,6 +83,7 @@ std::vector<long long> shard_critical_path(const Plan &P, int world, const std::
 int api_set_device(int d);
 int api_param_set_device(const april_graph_cholesky_param_t *param, int slot);
 int api_param_get_device(const april_graph_cholesky_param_t *param);
+void unbind_param(const april_graph_cholesky_param_t *param);
 int api_set_option(const char *name, double v);
 int api_get_option(const char *name, double *v);
 

@@ -346,6 +346,13 @@ int api_param_set_device(const april_graph_cholesky_param_t *param, int slot) {
     return 0;
 }
 int api_param_get_device(const april_graph_cholesky_param_t *param) { return physical_device(slot_for(param, nullptr)); }
+// a param that is re-initialised or destroyed loses its binding (another param allocated at the same address later must not inherit it)
+void unbind_param(const april_graph_cholesky_param_t *param) {
+    if (g_param_slot_n.load(std::memory_order_acquire) == 0) return;
+    std::lock_guard<std::mutex> lk(g_param_slot_mu);
+    g_param_slot.erase(param);
+    g_param_slot_n.store((int)g_param_slot.size(), std::memory_order_release);
+}
 int api_set_option(const char *name, double v) {
     load_env_options();
     const OptionDef *d = name ? find_option(name) : nullptr;

@@ -209,6 +209,8 @@ int aprilsam_amd_set_device(int device);
  * section 8(b) "Threading").  Calls on the same slot are serialised.  Whatever the param held (plan, fronts, captured graphs) is dropped;
  * a graph's device copies follow the slot of the param it is called with (one graph is driven from one slot at a time).  Options
  * (aprilsam_amd_set_option) stay process-global: set them while no call is in flight.  Returns 0, -1 for a bad slot.
+ * The binding lasts until april_graph_cholesky_param_init or _destory of that param (bind AFTER _init, as the example in
+ * INTEGRATION.md section 4b does): a param allocated later at the same address starts on the default slot.
  * aprilsam_amd_param_get_device: the HIP device a call on this param runs on. */
 int aprilsam_amd_param_set_device(const april_graph_cholesky_param_t *param, int slot);
 int aprilsam_amd_param_get_device(const april_graph_cholesky_param_t *param);

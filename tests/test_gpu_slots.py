@@ -102,4 +102,9 @@ def test_a_param_moved_to_another_slot_starts_from_scratch_and_bad_slots_are_ref
     assert p.stats()["symbolic_reused"] == 0
     assert abs(g.chi2() - oc[2]) < 1e-8 * oc[2] and np.max(np.abs(g.states() - ost)) < 1e-6
     assert lib.dll.aprilsam_amd_param_set_device(p.ptr, -1) == -1 and lib.dll.aprilsam_amd_param_set_device(p.ptr, 64) == -1
+    assert lib.dll.aprilsam_amd_param_set_device(p.ptr, 5) == 0
+    lib.dll.april_graph_cholesky_param_init(p.ptr)                   # a re-initialised param is back on the default slot
+    assert lib.dll.aprilsam_amd_param_get_device(p.ptr) == 0
+    g.cholesky(p)                                                    # and still solves there
+    assert np.isfinite(g.chi2()) and g.chi2() <= oc[2] * (1 + 1e-9)
     p.destroy(); g.destroy()
