@@ -87,6 +87,10 @@ struct DevPlan {
     long long *prof;              // debug: 8 wall-clock stamps (100 MHz) per front, or null
     int prof_mode;                // 1: stamps of the factorisation kernels, 2: of the back substitution
     int schur_first_nub;          // panel-mode small fronts with at least this many update blocks assemble their update columns AFTER the Schur product (0: never; see front_small_body)
+    // dependency flags of the batch path's multi-level launches carry the ITERATION NUMBER (see wait_flag): epoch = the counter k_linearize
+    // advances once per iteration (null: flags are 0 / 1 and reset before every launch -- the incremental path), flevel / l0 = fronts below
+    // level l0 are complete before the launch starts and are not waited for
+    int *epoch; const int *flevel; int l0;
 };
 
 // ---- work decomposition of the big-front kernels (shared by host launch tables and device decode) ----
@@ -425,13 +429,19 @@ __global__ void __launch_bounds__(TPB) k_linearize_t(int f_begin, int f_end, con
                                                    const unsigned char *__restrict__ swp, const int *__restrict__ slot_blk,
                                                    const int *__restrict__ slot_rhs, double *__restrict__ Hc, int *__restrict__ bad = nullptr,
                                                    const double *__restrict__ upt = nullptr, int nF = 0, const int *__restrict__ flevel = nullptr,
-                                                   int l0 = 0, int *__restrict__ flags = nullptr) {
+                                                   int l0 = 0, int *__restrict__ flags = nullptr, int *__restrict__ epoch = nullptr) {
     __shared__ double stg[STAGED ? TPB / 64 : 1][STAGED ? 64 * LIN_STRIDE : 1];
     __shared__ int sid[STAGED ? TPB / 64 : 1][STAGED ? 128 : 1];
     if (bad && blockIdx.x == 0 && threadIdx.x == 0) { bad[0] = 0; bad[1] = 0; bad[2] = 0; bad[3] = 0; }   // "not positive definite" record of this iteration
     // dependency flags of the multi-level launches (kernels below): fronts under the first multi-level level are complete
     // before that launch starts (1), the others publish themselves (0); the back substitution's flags all start at 0
-    if (flags) for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nF; t += gridDim.x * blockDim.x) { flags[t] = flevel[t] < l0 ? 1 : 0; flags[nF + t] = 0; }
+    // batch path (epoch): the flags carry the iteration number and are never reset -- this kernel only advances the counter, one kernel boundary
+    // before the first launch that reads it.  (A flag word is only ever touched by device-scope accesses: the reset below included.)
+    if (epoch) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(epoch, 1); }
+    else if (flags) for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nF; t += gridDim.x * blockDim.x) {
+        __hip_atomic_store(flags + t, flevel[t] < l0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flags + nF + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     linearise_factor<STAGED>(blockIdx.x * blockDim.x + threadIdx.x, f_begin, f_end, flist, fa, fb, Z, Wm, lp, st, swp, slot_blk, slot_rhs, Hc, upt, stg, sid);
 }
 
@@ -507,22 +517,36 @@ __device__ __forceinline__ void front_add(double *p, double v) {
     else *p += v;
 }
 
-// Dependency flags of the multi-level ("persistent") launches: a front that has finished publishes flag[t] = 1 after a
-// device-scope release fence; a dependent workgroup polls it with relaxed loads.  No deadlock by construction: the
-// launch lists are sorted so that every dependency has a LOWER workgroup id, and workgroups are dispatched in id
-// order -- the lowest unfinished workgroup always has all its dependencies finished, whatever else shares the GPU.  The
-// poll is bounded all the same (a front that gives up flags the iteration as failed instead of hanging the device).
+// Dependency flags of the multi-level ("persistent") launches: a front that has finished publishes its flag after a device-scope
+// release fence; a dependent workgroup polls it with relaxed loads.  No deadlock by construction: the launch lists are sorted so
+// that every dependency has a LOWER workgroup id, and workgroups are dispatched in id order -- the lowest unfinished workgroup
+// always has all its dependencies finished, whatever else shares the GPU.  The poll is bounded all the same (a front that gives
+// up flags the iteration as failed instead of hanging the device).
+// WHAT a flag holds (round 5).  Batch path: the ITERATION NUMBER -- a counter in device memory that k_linearize advances once per
+// iteration (DevPlan::epoch).  Flags are never reset: a value that is read late, or from a copy of the line that is not current,
+// is an OLDER iteration number and can only mean "not yet".  With flags that went 1 -> 0 (reset by plain stores in the kernel
+// before) -> 1 a soak of the API path showed about one solve in 10^4 on chain-like graphs (hundreds of tiny fronts, every level in
+// the multi-level launch) pass a wait on the PREVIOUS iteration's 1 and assemble a child's update block from the iteration before
+// -- wrong numbers or a spurious "not positive definite", no error (tools/soak_batch.py, profiles/r05_flag_soak.txt).  The
+// incremental path keeps 0 / 1 flags (its prologue decides per step which fronts count as done), reset with device-scope
+// stores like every other access to a flag word.
 // Polling uses RELAXED loads (an acquire load per poll would invalidate the XCD's L2 on every iteration and slow down every
 // workgroup running there); the caller then either reads the published data with agent-coherent loads (ld_agent) or
 // issues ONE acquire fence for the whole workgroup (acquire_all).
-__device__ __forceinline__ bool wait_flag(const int *flag, int *bad) {
+// ev != 0 (batch path): wait for exactly the iteration number; ev == 0 (paths that reset their flags to 0): wait for any other value
+__device__ __forceinline__ bool wait_flag(const int *flag, int *bad, int ev = 0) {
     int spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    for (;;) {
+        const int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ev ? v == ev : v != 0) break;
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1 << 23)) { if (atomicCAS(bad, 0, 9) == 0) { bad[2] = 9; bad[3] = 0; } return false; }      // flag value 9: not a pivot
     }
     return true;
 }
+// the value a finished front publishes and its dependants wait for: the iteration number on the batch path (read once, early: the load is
+// off the critical path by the time the value is needed), 0 = "flags are 0 / 1 and reset before the launch" on the other paths
+__device__ __forceinline__ int flag_value(const DevPlan &P) { return P.epoch ? __hip_atomic_load(P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; }
 // load that is coherent at agent scope without a fence: bypasses whatever stale copy of the line this XCD's L2 may hold
 // (global_load ... sc1).  Data written before another workgroup's publish_flag is visible to it once the flag is seen.
 __device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -531,10 +555,15 @@ __device__ __forceinline__ void acquire_all() {                 // after the pol
     if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __syncthreads();
 }
-__device__ __forceinline__ void publish_flag(int *flag) {       // call by ALL threads of the workgroup after their last store
-    __syncthreads();                                            // (every wave has waited for its stores to reach the L2)
-    if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // one L2 write-back for the workgroup
+__device__ __forceinline__ void publish_flag(int *flag, int ev = 0) {       // call by ALL threads of the workgroup after their last store
+    // every wave waits until ITS stores are in the L2: the barrier alone does not (a workgroup-scope release on gfx950 waits for no store,
+    // the compute unit's vector L1 keeps its waves' stores in order among themselves) and thread 0's write-back below waits only for its own wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, ev ? ev : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // one L2 write-back for the workgroup
 }
+// reset of a flag on the paths that reuse the values 0 / 1: a device-scope store like every other access to a flag word
+__device__ __forceinline__ void reset_flag(int *flag, int v) { __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // MODE: ASM_LDS    - every column of the chunk goes to dstL (LDS, leading dimension ldL)
 //       ASM_GLOBAL - every column goes to dstG (frontal array in HBM/L2, leading dimension ldG)
@@ -544,7 +573,7 @@ template <int NT, int MODE, bool ZERO = true>
 __device__ __forceinline__ void assemble_front(const DevPlan &P, const FrontDesc &D, const double *__restrict__ pool,
                                                const double *__restrict__ Hc, int bc0, int bc1, bool full,
                                                double *__restrict__ dstL, int ldL, double *__restrict__ dstG, int ldG, int2 *__restrict__ wl,
-                                               long long *pf = nullptr, const int *wait_flags = nullptr, int *bad = nullptr) {
+                                               long long *pf = nullptr, const int *wait_flags = nullptr, int *bad = nullptr, int ev = 0) {
     const int tid = threadIdx.x;
     const int nsb = D.nsb, nbc = D.nsb + D.nub;     // own / all block columns
     const int R = 3 * (nbc + 1);                    // rows incl. rhs block row
@@ -757,7 +786,10 @@ __device__ __forceinline__ void assemble_front(const DevPlan &P, const FrontDesc
         // needed from here on.  (Waiting child by child inside the extend-add, one acquire fence per wave and child, was
         // measured slower: an L2 invalidate is not cheap and hits every workgroup of the XCD.)
         if (wait_flags && !waited) {
-            for (int q = tid; q < nch; q += NT) wait_flag(wait_flags + (q < CAPQ ? crs[q].pad : P.child[D.ch_begin + q].pad), bad);
+            for (int q = tid; q < nch; q += NT) {
+                const int ct = q < CAPQ ? crs[q].pad : P.child[D.ch_begin + q].pad;
+                if (!P.epoch || P.flevel[ct] >= P.l0) wait_flag(wait_flags + ct, bad, ev);       // (children below the launch's first level finished in earlier launches)
+            }
             __syncthreads();                       // no acquire fence: the children's update blocks are read with ld_agent
             asm volatile("" ::: "memory");
             waited = true;
@@ -1083,6 +1115,7 @@ template <int NT>
 __device__ __forceinline__ void front_small_body(const DevPlan &P, const int t, double *__restrict__ pool, const double *__restrict__ Hc, int *bad,
                                                  long long full_lds_limit, int *flags, int wait, double *S) {
     const int *wflags = wait ? flags : nullptr;
+    const int ev = flags ? flag_value(P) : 0;
     const FrontDesc D = P.fd[t];
     const int nsb = D.nsb, nbc = D.nsb + D.nub;
     const int R = 3 * (nbc + 1), C = 3 * nbc, ld = R | 1;
@@ -1092,7 +1125,7 @@ __device__ __forceinline__ void front_small_body(const DevPlan &P, const int t, 
     if ((long long)small_front_lds(R, C, NT / 64) <= full_lds_limit) {
         int2 *wl = (int2 *)(S + (size_t)ld * C);
         if (P.prof && threadIdx.x == 0) P.prof[(size_t)t * PROF_SLOTS + 0] = wall_clock64();
-        assemble_front<NT, ASM_LDS>(P, D, pool, Hc, 0, nbc, true, S, ld, nullptr, 0, wl, P.prof ? P.prof + (size_t)t * PROF_SLOTS : nullptr, wflags, bad);
+        assemble_front<NT, ASM_LDS>(P, D, pool, Hc, 0, nbc, true, S, ld, nullptr, 0, wl, P.prof ? P.prof + (size_t)t * PROF_SLOTS : nullptr, wflags, bad, ev);
         if (P.prof && threadIdx.x == 0) P.prof[(size_t)t * PROF_SLOTS + 1] = wall_clock64();
         // rank-3 steps measured ~1.6x faster than the NB=32 blocked variant on LDS-resident fronts (chain-bound)
         factor_front_blk<NT>(S, ld, nsb, nbc, bad, (double *)wl, -1, P.prof ? P.prof + (size_t)t * PROF_SLOTS : nullptr);
@@ -1103,7 +1136,7 @@ __device__ __forceinline__ void front_small_body(const DevPlan &P, const int t, 
             int r0 = 3 * (c / 3);
             for (int r = r0 + (threadIdx.x & 63); r < R; r += 64) Fg[(size_t)c * R + r] = S[(size_t)c * ld + r];
         }
-        if (flags) publish_flag(flags + t);
+        if (flags) publish_flag(flags + t, ev);
         for (int c = threadIdx.x >> 6; c < 3 * nsb; c += NT / 64) {
             int r0 = 3 * (c / 3);
             for (int r = r0 + (threadIdx.x & 63); r < R; r += 64) Fg[(size_t)c * R + r] = S[(size_t)c * ld + r];
@@ -1117,8 +1150,8 @@ __device__ __forceinline__ void front_small_body(const DevPlan &P, const int t, 
         // them (no zero fill, no read-modify-write), and the factor blocks and the children's update blocks are added to it.
         const bool schur_first = P.schur_first_nub > 0 && D.nub >= P.schur_first_nub;
         if (P.prof && threadIdx.x == 0) P.prof[(size_t)t * PROF_SLOTS + 0] = wall_clock64();
-        if (schur_first) assemble_front<NT, ASM_SPLIT>(P, D, pool, Hc, 0, nsb, false, S, ld, Fg, R, wl, P.prof ? P.prof + (size_t)t * PROF_SLOTS : nullptr, wflags, bad);
-        else assemble_front<NT, ASM_SPLIT>(P, D, pool, Hc, 0, nbc, true, S, ld, Fg, R, wl, P.prof ? P.prof + (size_t)t * PROF_SLOTS : nullptr, wflags, bad);   // own columns -> LDS, update columns -> HBM/L2
+        if (schur_first) assemble_front<NT, ASM_SPLIT>(P, D, pool, Hc, 0, nsb, false, S, ld, Fg, R, wl, P.prof ? P.prof + (size_t)t * PROF_SLOTS : nullptr, wflags, bad, ev);
+        else assemble_front<NT, ASM_SPLIT>(P, D, pool, Hc, 0, nbc, true, S, ld, Fg, R, wl, P.prof ? P.prof + (size_t)t * PROF_SLOTS : nullptr, wflags, bad, ev);   // own columns -> LDS, update columns -> HBM/L2
         if (P.prof && threadIdx.x == 0) P.prof[(size_t)t * PROF_SLOTS + 1] = wall_clock64();
         factor_front_blk<NT>(S, ld, nsb, nbc, bad, (double *)wl, nsb, P.prof ? P.prof + (size_t)t * PROF_SLOTS : nullptr);
         if (P.prof && threadIdx.x == 0) P.prof[(size_t)t * PROF_SLOTS + 2] = wall_clock64();
@@ -1128,7 +1161,7 @@ __device__ __forceinline__ void front_small_body(const DevPlan &P, const int t, 
             assemble_front<NT, ASM_GLOBAL, false>(P, D, pool, Hc, nsb, nbc, false, nullptr, 0, Fg, R, wl, nullptr, nullptr, bad);
         }
         else if (nbc > nsb) lds_panel_syrk<NT, 1>(S, ld, 0, ns, ns, C, R - 2, Fg, R);      // Schur update, K = all own columns
-        if (flags) publish_flag(flags + t);                                              // the parent may go; the L panel follows
+        if (flags) publish_flag(flags + t, ev);                                          // the parent may go; the L panel follows
         for (int c = threadIdx.x >> 6; c < ns; c += NT / 64) {
             int r0 = 3 * (c / 3);
             for (int r = r0 + (threadIdx.x & 63); r < R; r += 64) Fg[(size_t)c * R + r] = S[(size_t)c * ld + r];
@@ -2039,10 +2072,10 @@ __host__ __device__ inline size_t backsolve_lds(int m, int ns, bool pre) { retur
 struct UpdArgs { const int *perm; const double *lp; double *st, *dX, *st_out, *dx_out; int *bad_out; double *lp_next; };      // lp_next (resident loops): the new state is also the next step's linearisation point (aprilsam.c:131-135) -- no copy between two steps
 // common tail of the back-substitution kernels: x of the own columns to HBM, flag for the children, then the state update
 // of the own poses (april_graph_xyt.c:302-314)
-__device__ __forceinline__ void backsolve_finish(const FrontDesc &D_, int t, const double *xw, double *__restrict__ x, int *xflags, int *bad, const UpdArgs &upd) {
+__device__ __forceinline__ void backsolve_finish(const FrontDesc &D_, int t, const double *xw, double *__restrict__ x, int *xflags, int *bad, const UpdArgs &upd, int ev = 0) {
     const int tid = threadIdx.x, nsb = D_.nsb, ns = 3 * nsb;
     for (int e = tid; e < ns; e += TPB) x[(size_t)3 * D_.first + e] = xw[e];
-    if (xflags) publish_flag(xflags + t);           // the children may go; the state update of the own poses follows
+    if (xflags) publish_flag(xflags + t, ev);       // the children may go; the state update of the own poses follows
     if (upd.perm) {
         for (int k = tid; k < nsb; k += TPB) {
             const int i = upd.perm[D_.first + k];
@@ -2080,6 +2113,7 @@ __global__ void __launch_bounds__(TPB) k_backsolve_t(DevPlan P, const int *__res
                                                      double *__restrict__ x, int split, int *xflags, int wait, int *bad, UpdArgs upd) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int t = fronts[blockIdx.x];
+    const int ev = xflags ? flag_value(P) : 0;
     const FrontDesc D_ = P.fd[t];
     const int nsb = D_.nsb, nub = D_.nub, nbc = nsb + nub;
     const int R = 3 * (nbc + 1), ns = 3 * nsb, m = 3 * nbc;
@@ -2105,7 +2139,7 @@ __global__ void __launch_bounds__(TPB) k_backsolve_t(DevPlan P, const int *__res
         }
     }
     if (wait && D_.parent >= 0) {          // multi-level launch, root first: x of every ancestor is final once the parent is done
-        if (tid == 0) wait_flag(xflags + D_.parent, bad);
+        if (tid == 0) wait_flag(xflags + D_.parent, bad, ev);
         if constexpr (PRE) { __syncthreads(); asm volatile("" ::: "memory"); }     // no acquire fence: x is gathered with ld_agent below
         else acquire_all();
     }
@@ -2251,7 +2285,7 @@ __global__ void __launch_bounds__(TPB) k_backsolve_t(DevPlan P, const int *__res
         if (pf) t_solve += wall_clock64() - ts;
     }
     if (pf && tid == 0) { pf[7] = wall_clock64(); pf[8] = t_prod; pf[9] = t_sum; pf[10] = t_solve; }
-    backsolve_finish(D_, t, xw, x, xflags, bad, upd);
+    backsolve_finish(D_, t, xw, x, xflags, bad, upd, ev);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2427,7 +2461,7 @@ __global__ void __launch_bounds__(TPB) k_backsolve_blk(DevPlan P, const int *__r
     }
     __syncthreads();
     // every helper has handed over all its blocks (each hand-over was waited for above), nobody polls any more: flags back to 0
-    for (int e = tid; e < 2 * BSB_MAXB; e += TPB) xflag[e] = 0;
+    for (int e = tid; e < 2 * BSB_MAXB; e += TPB) reset_flag(xflag + e, 0);
     backsolve_finish(D_, t, xw, x, nullptr, bad, upd);
 }
 
@@ -2447,6 +2481,7 @@ constexpr int BSW_MAX_NS = NB + 8 + NB * (NB + 1) - 256;     // own columns a fr
 template <int BSWT = BSW>
 __device__ __forceinline__ void backsolve_w_body(const DevPlan &P, const int t, const double *__restrict__ pool, double *__restrict__ x, int *xflags, int *bad,
                                                  const UpdArgs &upd, double *smem) {
+    const int ev = xflags ? flag_value(P) : 0;
     const FrontDesc D_ = P.fd[t];
     const int nsb = D_.nsb, nub = D_.nub, nbc = nsb + nub;
     const int R = 3 * (nbc + 1), ns = 3 * nsb, m = 3 * nbc;
@@ -2477,9 +2512,10 @@ __device__ __forceinline__ void backsolve_w_body(const DevPlan &P, const int t, 
         }
     }
     if (xflags && D_.parent >= 0) {                      // multi-level launch: x of every ancestor is final once the parent is done
-        if (tid == 0) wait_flag(xflags + D_.parent, bad);
+        if (tid == 0) wait_flag(xflags + D_.parent, bad, ev);
         __syncthreads();                                 // no acquire fence: x is gathered with ld_agent
         asm volatile("" ::: "memory");
+       
     }
     if (pf && tid == 0) pf[4] = wall_clock64();
     for (int e = tid; e < ns; e += TPB) xw[e] = Fg[(size_t)e * R + m];
@@ -2526,7 +2562,7 @@ __device__ __forceinline__ void backsolve_w_body(const DevPlan &P, const int t, 
         __syncthreads();
     }
     if (pf && tid == 0) pf[7] = wall_clock64();
-    backsolve_finish(D_, t, xw, x, xflags, bad, upd);
+    backsolve_finish(D_, t, xw, x, xflags, bad, upd, ev);
 }
 __global__ void __launch_bounds__(TPB) k_backsolve_w(DevPlan P, const int *__restrict__ fronts, const double *__restrict__ pool,
                                                      double *__restrict__ x, int *xflags, int *bad, UpdArgs upd) {
@@ -2627,12 +2663,12 @@ __device__ __forceinline__ void inc_prologue_body(const IncPrologue &a, const In
     }
     // dependency flags of the step's two multi-level launches: "factor done" of every front the sweep does not regenerate is
     // set (their parents poll all children), of the regenerated ones cleared; "x done" cleared for the fronts of the down sweep
-    if (fl.flags) for (int i = threadIdx.x; i < fl.n_fronts; i += nthr) fl.flags[i] = 1;
+    if (fl.flags) { for (int i = threadIdx.x; i < fl.n_fronts; i += nthr) reset_flag(fl.flags + i, 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // (in the L2 before the stores below)
     __syncthreads();                                    // (also: the patches above carry the two lists read below)
     if (a.stamps && threadIdx.x == 0) a.stamps[1] = wall_clock64();
     if (fl.flags) {
-        for (int i = threadIdx.x; i < fl.n_up; i += nthr) { fl.flags[fl.up_list[i]] = 0; fl.flags[2 * fl.n_fronts + fl.up_list[i]] = 0; }      // "done" and "vectors ready" (front_update_body)
-        for (int i = threadIdx.x; i < fl.n_dn; i += nthr) fl.flags[fl.n_fronts + fl.dn_list[i]] = 0;
+        for (int i = threadIdx.x; i < fl.n_up; i += nthr) { reset_flag(fl.flags + fl.up_list[i], 0); reset_flag(fl.flags + 2 * fl.n_fronts + fl.up_list[i], 0); }      // "done" and "vectors ready" (front_update_body)
+        for (int i = threadIdx.x; i < fl.n_dn; i += nthr) reset_flag(fl.flags + fl.n_fronts + fl.dn_list[i], 0);
     }
     if (f_end - f_begin > TAIL_MAXF) mirror = nullptr;
     for (int g0 = 0; g0 < f_end - f_begin; g0 += nthr)

@@ -53,7 +53,7 @@ def sweep_batch(lib, oracle, cases, option_sets, chi2_tol, state_tol, log=print)
             worst = max(worst, e1)
             log(f"{label} {o}: fronts {s['n_fronts']} levels {s['n_levels']} rows {s['max_front_rows']} chi2 relerr {e1:.2e} states {e2:.2e}")
             assert s["error_code"] == 0 and s["not_spd"] == 0, (label, o, s)
-            assert e1 < chi2_tol and e2 < state_tol, ("MISMATCH", label, o, e1, e2)
+            assert e1 < chi2_tol and e2 < state_tol, ("MISMATCH", label, o, e1, e2, c.tolist(), oc.tolist(), s)
     return worst
 
 
