@@ -70,3 +70,55 @@ def compare_traces(ours, ref):
     ec = max(abs(a[0] - b[0]) / max(b[0], 1.0) for a, b in zip(ours, ref))
     es = max(float(np.max(np.abs(a[1] - b[1]))) for a, b in zip(ours, ref))
     return ec, es
+
+
+# ---- soak of the batch API path (tools/soak_batch.py; a bounded slice runs under -m gpu) --------------------------------------
+SOAK_KINDS = [("chain", 1500), ("chain", 97), ("star", 700), ("star", 130), ("complete", 60), ("complete", 140), ("two", 900), ("band", 1100), ("band", 257), ("comb", 1300)]
+SOAK_OPTIONS = [dict(), dict(), dict(), dict(small_lds_kb=0), dict(small_lds_kb=16, leaf_nodes=6)]
+
+
+def soak_cases():
+    cases = [(f"{k} n={n}", structured(k, n, 300 + i)) for i, (k, n) in enumerate(SOAK_KINDS)]
+    return cases + [(f"random {i}", datasets.random_pose_graph(int(n), int(m), 50 + i)) for i, (n, m) in enumerate([(300, 400), (900, 800), (1500, 900), (2500, 2000)])]
+
+
+def soak_run(lib, arr):
+    """two april_graph_cholesky calls on a fresh graph + param: chi^2 trace, final states, last stats + (not_spd, reused, ran twice) per call"""
+    g = lib.new_graph(); g.build_from_arrays(*arr); p = lib.new_param()
+    chi2 = [g.chi2()]; flags = []
+    for _ in range(2):
+        g.cholesky(p); chi2.append(g.chi2()); s = p.stats(); flags.append((s["not_spd"], s["symbolic_reused"], s["reserved1"]))
+    st = g.states(); p.destroy(); g.destroy()
+    s["calls"] = flags
+    return np.array(chi2), st, s
+
+
+def soak(lib, seconds, seed, log=print, cases=None, focus=False):
+    """cases in random order until the time is up, every result compared BITWISE with the first of its (case, options); a run that
+    differs is repeated at once (transient or persistent?).  Returns (runs, differing runs)."""
+    import time
+    rng = np.random.default_rng(seed)
+    cases = cases or soak_cases()
+    optsets = [dict()] * 8 + SOAK_OPTIONS[3:] if focus else SOAK_OPTIONS
+    first = {}; runs = 0; bad = 0; t0 = time.time(); t_rep = t0; prev = None
+    while time.time() - t0 < seconds:
+        ci = int(rng.integers(len(cases))); oi = int(rng.integers(len(optsets)))
+        if focus and rng.random() < 0.5: ci = 0 if rng.random() < 0.5 else 7
+        label, arr = cases[ci]; o = optsets[oi]
+        with lib.options(**o):
+            c, st, s = soak_run(lib, arr)
+        key = (ci, tuple(sorted(o.items())))
+        was, prev = prev, (label, o)
+        runs += 1
+        if key not in first: first[key] = (c, st); continue
+        if not (np.array_equal(c, first[key][0]) and np.array_equal(st, first[key][1])) or s["error_code"]:
+            bad += 1
+            e2 = float(np.max(np.abs(st - first[key][1])))
+            with lib.options(**o):
+                c2, st2, s2 = soak_run(lib, arr)
+            again = np.array_equal(c2, first[key][0]) and np.array_equal(st2, first[key][1])
+            log(f"run {runs} t={time.time() - t0:.1f}s DIFFERENT: {label} {o}: chi2 {c.tolist()} expected {first[key][0].tolist()} max state diff {e2:.3e} "
+                f"error_code {s['error_code']} (not_spd, reused, ran twice) per call {s['calls']} fronts {s['n_fronts']} levels {s['n_levels']} previous run {was}; "
+                f"re-run at once {'matches again' if again else 'STILL different: ' + str(c2.tolist())}")
+        if time.time() - t_rep > 30: t_rep = time.time(); log(f"  {runs} runs, {bad} different, {time.time() - t0:.0f} s")
+    return runs, bad
