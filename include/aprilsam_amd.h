@@ -333,7 +333,7 @@ void aprilsam_amd_clear_error(void);
  *                       per-front dependency flags (which carry the iteration number and are never reset: round 5 found fronts of
  *                       such a launch passing a wait on the previous iteration's flag about once in 10^4 solves of chain-like graphs,
  *                       profiles/r05_flag_soak.txt); 0 = one launch per level, no flags -- the conservative setting, M3500 then
- *                       costs about a fifth more per iteration
+ *                       costs about a quarter more per iteration (what the multi-level launches bought when they were introduced: 0.366 -> 0.294 ms)
  *   "blk_backsolve"     1 (default): multi-workgroup fronts are back-substituted 128 columns at a time by a chain
  *                       workgroup + helper workgroups, with the inverse diagonal blocks the factorisation left behind; 0 = one
  *                       workgroup per front, 32 columns at a time
