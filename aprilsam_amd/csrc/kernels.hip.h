@@ -560,7 +560,16 @@ __device__ __forceinline__ void publish_flag(int *flag, int ev = 0) {       // c
     // the compute unit's vector L1 keeps its waves' stores in order among themselves) and thread 0's write-back below waits only for its own wave
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flag, ev ? ev : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // one L2 write-back for the workgroup
+    if (threadIdx.x == 0) {
+        // The release, WRITTEN OUT: write back the XCD's L2 (one write-back for the workgroup), WAIT for it, then the flag.  As an
+        // __ATOMIC_RELEASE store the compiler (hipcc of ROCm 7.2, gfx950) emitted buffer_wbl2 and the store WITHOUT the s_waitcnt between them at
+        // 9 of this file's 24 release sites -- wherever it saw no other vector memory operation pending, among them the full-LDS branch of
+        // front_small_body and k_backsolve_w: the flag could reach memory before the update block / x it announces, and a dependant on another
+        // XCD then read what the addresses held BEFORE (the iteration or the context before).  This is what the soak of round 5 was
+        // seeing: only graphs whose fronts all take those two branches differed (profiles/r05_flag_soak.txt).
+        asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __hip_atomic_store(flag, ev ? ev : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 // reset of a flag on the paths that reuse the values 0 / 1: a device-scope store like every other access to a flag word
 __device__ __forceinline__ void reset_flag(int *flag, int v) { __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -2881,7 +2890,10 @@ __global__ void __launch_bounds__(NT) k_inc_one(IncPrologue a, IncFlags fl, Inli
     if (a.done) {                                       // every thread's stores to the pinned mirrors are performed before the word goes out
         __threadfence_system();
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(a.done, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) {        // (release written out, see publish_flag)
+            asm volatile("buffer_wbl2 sc0 sc1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __hip_atomic_store(a.done, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 // states AND l_points from the pinned mirrors (incremental steps keep the nodes' l_points, aprilsam.c:377-576)
