@@ -524,10 +524,8 @@ __device__ __forceinline__ void front_add(double *p, double v) {
 // up flags the iteration as failed instead of hanging the device).
 // WHAT a flag holds (round 5).  Batch path: the ITERATION NUMBER -- a counter in device memory that k_linearize advances once per
 // iteration (DevPlan::epoch).  Flags are never reset: a value that is read late, or from a copy of the line that is not current,
-// is an OLDER iteration number and can only mean "not yet".  With flags that went 1 -> 0 (reset by plain stores in the kernel
-// before) -> 1 a soak of the API path showed about one solve in 10^4 on chain-like graphs (hundreds of tiny fronts, every level in
-// the multi-level launch) pass a wait on the PREVIOUS iteration's 1 and assemble a child's update block from the iteration before
-// -- wrong numbers or a spurious "not positive definite", no error (tools/soak_batch.py, profiles/r05_flag_soak.txt).  The
+// is an OLDER iteration number and can only mean "not yet".  (Introduced while hunting the wrong results of profiles/r05_flag_soak.txt, whose
+// cause turned out to be the release sequence -- see publish_flag; kept because it removes the reset from the protocol altogether.)  The
 // incremental path keeps 0 / 1 flags (its prologue decides per step which fronts count as done), reset with device-scope
 // stores like every other access to a flag word.
 // Polling uses RELAXED loads (an acquire load per poll would invalidate the XCD's L2 on every iteration and slow down every

@@ -330,9 +330,9 @@ void aprilsam_amd_clear_error(void);
  *   "tail_poses"        own poses per tail front of the incremental path (default 28, at least 8)
  *   "persist"           1 (default): the top levels of the elimination tree -- as many as hold at most "persist_max_fronts"
  *                       (default 240) single-workgroup fronts -- run as ONE launch per sweep, fronts synchronised by
- *                       per-front dependency flags (which carry the iteration number and are never reset: round 5 found fronts of
- *                       such a launch passing a wait on the previous iteration's flag about once in 10^4 solves of chain-like graphs,
- *                       profiles/r05_flag_soak.txt); 0 = one launch per level, no flags -- the conservative setting, M3500 then
+ *                       per-front dependency flags (round 5 found and fixed a release in these launches that did not wait for its L2
+ *                       write-back -- a wrong result about once in 10^4 solves of chain-like graphs, profiles/r05_flag_soak.txt);
+ *                       0 = one launch per level, no flags -- the conservative setting, M3500 then
  *                       costs about a quarter more per iteration (what the multi-level launches bought when they were introduced: 0.366 -> 0.294 ms)
  *   "blk_backsolve"     1 (default): multi-workgroup fronts are back-substituted 128 columns at a time by a chain
  *                       workgroup + helper workgroups, with the inverse diagonal blocks the factorisation left behind; 0 = one
