@@ -10,9 +10,11 @@
 //   reset = 1  the same, reset by device-scope stores
 //   reset = 2  flags carry the round number (a counter in device memory that A advances), never reset  (the solver now)
 //   wait  = 1  every wave waits for its own stores (s_waitcnt vmcnt(0)) before the publishing barrier
+//   release = 0  the flag's release as the compiler emitted it at 9 of the solver's 24 sites before the fix: buffer_wbl2 and the store with NO
+//                s_waitcnt between them;  1 = write-back, wait, store
 // A wrong data word is classified by the child's marker: marker != round -> the wait passed before the child published in this round
 // ("early"); marker == round -> the flag was right and the data word was not ("stale data").  A counter that reads back old is "stale epoch".
-//   usage: flag_handover [seconds per configuration]
+//   usage: flag_handover [seconds per configuration] [configurations: the first n of {before the fix, after, ...}]
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -37,7 +39,7 @@ __global__ void __launch_bounds__(256) k_prepare(int *flags, int *epoch, int *sc
     scratch[t] = round;                 // (the other stores of the kernel before)
 }
 
-__global__ void __launch_bounds__(W) k_tree(int *flags, const int *epoch, int *data, int *marker, int reset, int wait_stores, int round, Counts *cnt) {
+__global__ void __launch_bounds__(W) k_tree(int *flags, const int *epoch, int *data, int *marker, int reset, int wait_stores, int release, int round, Counts *cnt) {
     const int t = blockIdx.x, tid = threadIdx.x;
     // children of node t in a bottom-up numbering: leaves 0..127, then 64 nodes 128..191 with children (2 k, 2 k + 1), ...
     int c0 = -1, c1 = -1;
@@ -75,7 +77,9 @@ __global__ void __launch_bounds__(W) k_tree(int *flags, const int *epoch, int *d
     if (wait_stores) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __hip_atomic_store(flags + t, reset == 2 ? ev : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (release) asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tbuffer_wbl2 sc1" ::: "memory");
+        __hip_atomic_store(flags + t, reset == 2 ? ev : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(marker + t, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -86,9 +90,11 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&flags, NWG * 4)); CK(hipMalloc(&epoch, 4)); CK(hipMalloc(&data, NWG * W * 4)); CK(hipMalloc(&marker, NWG * 4));
     CK(hipMalloc(&scratch, 18 * 256 * 4)); CK(hipMalloc(&cnt, sizeof(Counts)));
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    const int cfg[][2] = { { 0, 0 }, { 1, 0 }, { 2, 0 }, { 2, 1 }, { 0, 1 } };
-    for (auto &c : cfg) {
-        const int reset = c[0], wait_stores = c[1];
+    const int all[][3] = { { 0, 0, 0 }, { 2, 1, 1 }, { 0, 0, 1 }, { 2, 1, 0 }, { 1, 0, 1 } };
+    const int ncfg = argc > 2 ? atoi(argv[2]) : 5;
+    for (int q = 0; q < ncfg && q < 5; q++) {
+        const int *c = all[q];
+        const int reset = c[0], wait_stores = c[1], release = c[2];
         const int e0 = EPOCH0;
         CK(hipMemsetAsync(flags, 0, NWG * 4, s)); CK(hipMemsetAsync(data, 0, NWG * W * 4, s)); CK(hipMemsetAsync(marker, 0, NWG * 4, s));
         CK(hipMemsetAsync(cnt, 0, sizeof(Counts), s)); CK(hipMemcpyAsync(epoch, &e0, 4, hipMemcpyHostToDevice, s)); CK(hipStreamSynchronize(s));
@@ -97,13 +103,14 @@ int main(int argc, char **argv) {
             for (int k = 0; k < 2000; k++) {
                 round++;
                 hipLaunchKernelGGL(k_prepare, dim3(18), dim3(256), 0, s, flags, epoch, scratch, reset, round);
-                hipLaunchKernelGGL(k_tree, dim3(NWG), dim3(W), 0, s, flags, epoch, data, marker, reset, wait_stores, round, cnt);
+                hipLaunchKernelGGL(k_tree, dim3(NWG), dim3(W), 0, s, flags, epoch, data, marker, reset, wait_stores, release, round, cnt);
             }
             CK(hipStreamSynchronize(s));
         }
         Counts h; CK(hipMemcpy(&h, cnt, sizeof(h), hipMemcpyDeviceToHost));
-        printf("reset %d (%s) wait_stores %d: %d rounds in %.1f s, %llu hand-overs: early %llu, stale data %llu, stale epoch %llu, timeouts %llu\n", reset,
-               reset == 0 ? "0/1 flags, plain reset" : reset == 1 ? "0/1 flags, device-scope reset" : "round number, never reset", wait_stores, round, now_s() - t0,
+        printf("reset %d (%s) wait_stores %d release %s: %d rounds in %.1f s, %llu hand-overs: early %llu, stale data %llu, stale epoch %llu, timeouts %llu\n", reset,
+               reset == 0 ? "0/1 flags, plain reset" : reset == 1 ? "0/1 flags, device-scope reset" : "round number, never reset", wait_stores,
+               release ? "wbl2+wait+store" : "wbl2+store (no wait)", round, now_s() - t0,
                h.handovers, h.early, h.stale_data, h.stale_epoch, h.timeout);
         fflush(stdout);
     }
