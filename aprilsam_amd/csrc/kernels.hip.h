@@ -561,10 +561,11 @@ __device__ __forceinline__ void publish_flag(int *flag, int ev = 0) {       // c
     if (threadIdx.x == 0) {
         // The release, WRITTEN OUT: write back the XCD's L2 (one write-back for the workgroup), WAIT for it, then the flag.  As an
         // __ATOMIC_RELEASE store the compiler (hipcc of ROCm 7.2, gfx950) emitted buffer_wbl2 and the store WITHOUT the s_waitcnt between them at
-        // 9 of this file's 24 release sites -- wherever it saw no other vector memory operation pending, among them the full-LDS branch of
-        // front_small_body and k_backsolve_w: the flag could reach memory before the update block / x it announces, and a dependant on another
-        // XCD then read what the addresses held BEFORE (the iteration or the context before).  This is what the soak of round 5 was
-        // seeing: only graphs whose fronts all take those two branches differed (profiles/r05_flag_soak.txt).
+        // 7 of this file's 24 release sites -- wherever it had no other vector memory operation on its books at that point -- among them the
+        // full-LDS branch of front_small_body: the flag could reach memory before the update block it announces, and a dependant on another XCD
+        // then read what the addresses held BEFORE (the iteration or the context before).  That is the defect behind the rare wrong results
+        // of chain-like graphs, whose fronts all take that branch (profiles/r05_flag_soak.txt, listings in profiles/r05_release_isa.txt;
+        // tools/check_release_isa.py checks every release of the generated code).
         asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __hip_atomic_store(flag, ev ? ev : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

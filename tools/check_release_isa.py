@@ -2,7 +2,7 @@
 """Every release in the device code must be  buffer_wbl2 -> s_waitcnt vmcnt(0) -> store.
 
 hipcc of ROCm 7.2 drops the s_waitcnt between the L2 write-back and the released store where it sees no other vector memory operation
-pending (9 of the 24 release sites of kernels.hip.h when they were written as __ATOMIC_RELEASE stores): the flag of a multi-level launch
+pending (7 of the 24 release sites of kernels.hip.h when they were written as __ATOMIC_RELEASE stores, profiles/r05_release_isa.txt): the flag of a multi-level launch
 could then reach memory before the data it announces -- the wrong results of profiles/r05_flag_soak.txt.  publish_flag writes the sequence out
 in inline assembly since; this script compiles the device code to assembly and checks every buffer_wbl2 of every kernel, so that a release
 added later the ordinary way cannot bring the defect back unnoticed.
