@@ -87,10 +87,12 @@ struct DevPlan {
     long long *prof;              // debug: 8 wall-clock stamps (100 MHz) per front, or null
     int prof_mode;                // 1: stamps of the factorisation kernels, 2: of the back substitution
     int schur_first_nub;          // panel-mode small fronts with at least this many update blocks assemble their update columns AFTER the Schur product (0: never; see front_small_body)
-    // dependency flags of the batch path's multi-level launches carry the ITERATION NUMBER (see wait_flag): epoch = the counter k_linearize
-    // advances once per iteration (null: flags are 0 / 1 and reset before every launch -- the incremental path), flevel / l0 = fronts below
-    // level l0 are complete before the launch starts and are not waited for
-    int *epoch; const int *flevel; int l0;
+    // dependency flags of ALL multi-level launches carry the STEP NUMBER (see wait_flag): epoch = the counter the first kernel of every numeric
+    // phase advances (k_linearize: a batch iteration; the prologue: an incremental step).  Nothing is ever reset.  Which children a front waits for:
+    //   flevel / l0 (batch sweeps): fronts below level l0 are complete before the launch starts and are not waited for;
+    //   marks (incremental steps, else null): marks[t] == step number <=> front t is regenerated by THIS step's launch (written by the prologue,
+    //   one kernel boundary earlier -- data, not a flag: an older value means "not in this step", its factor of an earlier step is what is wanted).
+    int *epoch; const int *flevel; int l0; const int *marks;
 };
 
 // ---- work decomposition of the big-front kernels (shared by host launch tables and device decode) ----
@@ -428,20 +430,13 @@ __global__ void __launch_bounds__(TPB) k_linearize_t(int f_begin, int f_end, con
                                                    const double *__restrict__ lp, const double *__restrict__ st,
                                                    const unsigned char *__restrict__ swp, const int *__restrict__ slot_blk,
                                                    const int *__restrict__ slot_rhs, double *__restrict__ Hc, int *__restrict__ bad = nullptr,
-                                                   const double *__restrict__ upt = nullptr, int nF = 0, const int *__restrict__ flevel = nullptr,
-                                                   int l0 = 0, int *__restrict__ flags = nullptr, int *__restrict__ epoch = nullptr) {
+                                                   const double *__restrict__ upt = nullptr, int *__restrict__ epoch = nullptr) {
     __shared__ double stg[STAGED ? TPB / 64 : 1][STAGED ? 64 * LIN_STRIDE : 1];
     __shared__ int sid[STAGED ? TPB / 64 : 1][STAGED ? 128 : 1];
     if (bad && blockIdx.x == 0 && threadIdx.x == 0) { bad[0] = 0; bad[1] = 0; bad[2] = 0; bad[3] = 0; }   // "not positive definite" record of this iteration
-    // dependency flags of the multi-level launches (kernels below): fronts under the first multi-level level are complete
-    // before that launch starts (1), the others publish themselves (0); the back substitution's flags all start at 0
-    // batch path (epoch): the flags carry the iteration number and are never reset -- this kernel only advances the counter, one kernel boundary
-    // before the first launch that reads it.  (A flag word is only ever touched by device-scope accesses: the reset below included.)
-    if (epoch) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(epoch, 1); }
-    else if (flags) for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nF; t += gridDim.x * blockDim.x) {
-        __hip_atomic_store(flags + t, flevel[t] < l0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(flags + nF + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // dependency flags of the multi-level launches (kernels below) carry the step number and are never reset: this kernel only advances the
+    // counter, one kernel boundary before the first launch that reads it
+    if (epoch && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(epoch, 1);
     linearise_factor<STAGED>(blockIdx.x * blockDim.x + threadIdx.x, f_begin, f_end, flist, fa, fb, Z, Wm, lp, st, swp, slot_blk, slot_rhs, Hc, upt, stg, sid);
 }
 
@@ -522,16 +517,17 @@ __device__ __forceinline__ void front_add(double *p, double v) {
 // that every dependency has a LOWER workgroup id, and workgroups are dispatched in id order -- the lowest unfinished workgroup
 // always has all its dependencies finished, whatever else shares the GPU.  The poll is bounded all the same (a front that gives
 // up flags the iteration as failed instead of hanging the device).
-// WHAT a flag holds (round 5).  Batch path: the ITERATION NUMBER -- a counter in device memory that k_linearize advances once per
-// iteration (DevPlan::epoch).  Flags are never reset: a value that is read late, or from a copy of the line that is not current,
-// is an OLDER iteration number and can only mean "not yet".  (Introduced while hunting the wrong results of profiles/r05_flag_soak.txt, whose
-// cause turned out to be the release sequence -- see publish_flag; kept because it removes the reset from the protocol altogether.)  The
-// incremental path keeps 0 / 1 flags (its prologue decides per step which fronts count as done), reset with device-scope
-// stores like every other access to a flag word.
+// WHAT a flag holds.  The STEP NUMBER -- a counter in device memory (DevPlan::epoch) that the first kernel of every numeric phase advances:
+// k_linearize once per batch iteration (round 5), the prologue once per incremental step (round 6: the incremental path's launches used 0 / 1
+// flags that the prologue reset every step).  Flags are never reset: a value that is read late, or from a copy of the line that is not current,
+// is an OLDER step number and can only mean "not yet".  (Introduced while hunting the wrong results of profiles/r05_flag_soak.txt, whose
+// cause turned out to be the release sequence -- see publish_flag; kept because it removes the reset from the protocol altogether.)  The one
+// exception is k_backsolve_blk, whose chain and helper workgroups hand blocks to each other INSIDE one launch through 0 / 1 words that the chain
+// resets before the launch ends (ev == 0 below): several launches of one step share the words, separated by kernel boundaries.
 // Polling uses RELAXED loads (an acquire load per poll would invalidate the XCD's L2 on every iteration and slow down every
 // workgroup running there); the caller then either reads the published data with agent-coherent loads (ld_agent) or
 // issues ONE acquire fence for the whole workgroup (acquire_all).
-// ev != 0 (batch path): wait for exactly the iteration number; ev == 0 (paths that reset their flags to 0): wait for any other value
+// ev != 0: wait for exactly the step number; ev == 0 (k_backsolve_blk's self-resetting words): wait for any other value
 __device__ __forceinline__ bool wait_flag(const int *flag, int *bad, int ev = 0) {
     int spins = 0;
     for (;;) {
@@ -796,7 +792,8 @@ __device__ __forceinline__ void assemble_front(const DevPlan &P, const FrontDesc
         if (wait_flags && !waited) {
             for (int q = tid; q < nch; q += NT) {
                 const int ct = q < CAPQ ? crs[q].pad : P.child[D.ch_begin + q].pad;
-                if (!P.epoch || P.flevel[ct] >= P.l0) wait_flag(wait_flags + ct, bad, ev);       // (children below the launch's first level finished in earlier launches)
+                // children that are not part of this launch finished earlier: below its first level (batch sweeps), or not regenerated by this step
+                if (P.marks ? __hip_atomic_load(P.marks + ct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ev : P.flevel[ct] >= P.l0) wait_flag(wait_flags + ct, bad, ev);
             }
             __syncthreads();                       // no acquire fence: the children's update blocks are read with ld_agent
             asm volatile("" ::: "memory");
@@ -1235,6 +1232,7 @@ __device__ __forceinline__ void front_update_body(const DevPlan &P, const int t,
     double *Cm = Wa + 3 * nsp;                       // Cholesky factor of I + P^T P (6 values)
     long long *pf = P.prof ? P.prof + (size_t)t * PROF_SLOTS : nullptr;
     if (pf && tid == 0) pf[0] = wall_clock64();
+    const int ev = (flags || uc.wflags) ? flag_value(P) : 0;      // the step number every flag of this launch carries
     // ---- 1. the old panel -> LDS in the new layout (zeros above the diagonal and in rows the structure gained) ----------------
     {
         const int ne = ns * R;
@@ -1310,7 +1308,7 @@ __device__ __forceinline__ void front_update_body(const DevPlan &P, const int t,
         pre_dst[k] = (k < rec.n_ch && e < cnu3) ? P.f_rel[rec.ch_rel[kk] + e / 3] : 0;
     }
     if (uc.wflags && rec.n_ch > 0) {                 // multi-level launch: the children's vectors
-        if (tid < rec.n_ch) wait_flag(uc.wflags + rec.ch_t[tid], bad);
+        if (tid < rec.n_ch) wait_flag(uc.wflags + rec.ch_t[tid], bad, ev);
         __syncthreads();
         asm volatile("" ::: "memory");
     }
@@ -1430,7 +1428,7 @@ __device__ __forceinline__ void front_update_body(const DevPlan &P, const int t,
         }
         if (si == nact - 1 && uc.wflags) {
             if (pf && tid == 0) pf[2] = wall_clock64();
-            publish_flag(uc.wflags + t);             // (its barrier also separates the reads above from the writes below)
+            publish_flag(uc.wflags + t, ev);         // (its barrier also separates the reads above from the writes below)
         } else __syncthreads();                      // (row r was read above by thread r - ns and is written below by thread r)
         // (d) the rows: residual and new entries, column after column (own rows stop at the diagonal); the update rows end with
         //     their W~ once more, this time kept in LDS for the update block below
@@ -1496,7 +1494,7 @@ __device__ __forceinline__ void front_update_body(const DevPlan &P, const int t,
         const int r0 = 3 * (c / 3);
         for (int r = r0 + lane; r < R; r += 64) Fg[(size_t)c * R + r] = Ls[(size_t)c * ld + r];
     }
-    if (flags) publish_flag(flags + t);
+    if (flags) publish_flag(flags + t, ev);
     if (pf) { __syncthreads(); if (tid == 0) pf[3] = wall_clock64(); }
 }
 
@@ -2600,6 +2598,26 @@ __global__ void __launch_bounds__(TPB) k_guard(int mode, const long long *__rest
     }
     if (bad) { atomicAdd(count, bad); count[1] = b; }
 }
+// Debug option pool_poison: before a step, everything a multi-level launch hands from one workgroup to another is filled with NaN -- the
+// UPDATE block of every front the step (re)factorises (what its parent's extend-add reads) and x at its own positions (what its children's
+// back substitution gathers).  A dependency wait that passes early then yields NaN / "not positive definite" with certainty instead of
+// the previous step's numbers, which are the right ones whenever the previous step solved the same system (the mask that hid round 5's
+// release defect from every test but the soak).  list == null: fronts 0 .. n-1.  what: bit 0 = update blocks, bit 1 = x.  skip_mode (an
+// incremental step's update records, or null): entries with mode != 0 are UPDATED in place from their old factor, not re-assembled -- left alone.
+__global__ void __launch_bounds__(TPB) k_poison(DevPlan P, const int *__restrict__ list, int n, const int *__restrict__ skip_mode, int skip_stride, int what,
+                                                double *__restrict__ pool, double *__restrict__ x) {
+    if ((int)blockIdx.x >= n) return;
+    if (skip_mode && skip_mode[(size_t)blockIdx.x * skip_stride]) return;
+    const int t = list ? list[blockIdx.x] : (int)blockIdx.x;
+    const FrontDesc D = P.fd[t];
+    const int nbc = D.nsb + D.nub, R = 3 * (nbc + 1), ns = 3 * D.nsb, C = 3 * nbc;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    double *Fg = pool + D.off;
+    if (what & 1)
+        for (int c = ns + (threadIdx.x >> 6); c < C; c += TPB / 64)
+            for (int r = 3 * (c / 3) + (threadIdx.x & 63); r < R - 2; r += 64) Fg[(size_t)c * R + r] = qnan;
+    if (what & 2) for (int e = threadIdx.x; e < ns; e += TPB) x[(size_t)3 * D.first + e] = qnan;
+}
 __global__ void __launch_bounds__(TPB) k_pack_update(double *__restrict__ front, int R, int ns, double *__restrict__ buf, int dir) {
     const int j = ns + blockIdx.x, Rv = R - 2, r0 = j / 3 * 3;
     double *__restrict__ col = front + (size_t)j * R;
@@ -2628,7 +2646,9 @@ __global__ void __launch_bounds__(TPB) k_apply_patches(const Patch *__restrict__
 // thread per new factor.  What the barrier orders is this workgroup's own global stores against its own global loads: the
 // compute unit's vector L1 is shared by its waves and written through, nothing here goes through the scalar cache.
 // Saves two launches per step (about 4 us of host time and a few us of GPU idle time each).
-struct IncFlags { int *flags; int n_fronts; const int *up_list; int n_up; const int *dn_list; int n_dn; };
+// epoch: the step counter the prologue advances (every flag of the step's launches carries the new value); marks / up_list: the fronts the
+// step's multi-level launch regenerates get marks[t] = the new value (assemble_front waits for exactly those children), or null
+struct IncFlags { int *epoch; int *marks; const int *up_list; int n_up; };
 constexpr int INL_PATCHES = 24, INL_BYTES = 2048;      // a small step's patches travel in the kernel arguments: no PCIe read on the kernel's path
 // Third argument of k_inc_prologue / k_inc_one.  Never touched by name in device code (a by-value aggregate that is indexed
 // dynamically gets copied to scratch, all 2.6 KB of it per lane): read through the kernel-argument segment pointer instead.
@@ -2669,15 +2689,14 @@ __device__ __forceinline__ void inc_prologue_body(const IncPrologue &a, const In
             for (long long i = lane; i < p.bytes; i += 64) dst[i] = src[i];
         }
     }
-    // dependency flags of the step's two multi-level launches: "factor done" of every front the sweep does not regenerate is
-    // set (their parents poll all children), of the regenerated ones cleared; "x done" cleared for the fronts of the down sweep
-    if (fl.flags) { for (int i = threadIdx.x; i < fl.n_fronts; i += nthr) reset_flag(fl.flags + i, 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // (in the L2 before the stores below)
-    __syncthreads();                                    // (also: the patches above carry the two lists read below)
+    // dependency flags of the step's two multi-level launches: nothing is reset -- the step counter advances, a finished front publishes the
+    // new number, and the fronts this step regenerates are marked with it (a parent waits for exactly those children; the factors of the
+    // others are older and complete)
+    __shared__ int s_ev;
+    if (fl.epoch && threadIdx.x == 0) s_ev = atomicAdd(fl.epoch, 1) + 1;
+    __syncthreads();                                    // (also: the patches above carry the list read below)
     if (a.stamps && threadIdx.x == 0) a.stamps[1] = wall_clock64();
-    if (fl.flags) {
-        for (int i = threadIdx.x; i < fl.n_up; i += nthr) { reset_flag(fl.flags + fl.up_list[i], 0); reset_flag(fl.flags + 2 * fl.n_fronts + fl.up_list[i], 0); }      // "done" and "vectors ready" (front_update_body)
-        for (int i = threadIdx.x; i < fl.n_dn; i += nthr) reset_flag(fl.flags + fl.n_fronts + fl.dn_list[i], 0);
-    }
+    if (fl.marks) for (int i = threadIdx.x; i < fl.n_up; i += nthr) reset_flag(fl.marks + fl.up_list[i], s_ev);
     if (f_end - f_begin > TAIL_MAXF) mirror = nullptr;
     for (int g0 = 0; g0 < f_end - f_begin; g0 += nthr)
         linearise_factor<false>(g0 + (int)threadIdx.x, f_begin, f_end, nullptr, fa, fb, Z, Wm, lp, st, swp, slot_blk, slot_rhs, Hc, nullptr, nullptr, nullptr, mirror);

@@ -71,7 +71,7 @@ static const OptionDef OPTION_TABLE[] = {
     { "persist_max_fronts", &Options::persist_max_fronts, 0, false }, { "linearize_staged_min", &Options::linearize_staged_min, 0, false },
     { "wave_backsolve", &Options::wave_backsolve, 0, false }, { "blk_backsolve", &Options::blk_backsolve, 0, false }, { "tail_poses", &Options::tail_poses, 8, false },
     { "batch_extend", &Options::batch_extend, 0, true }, { "extend_tail_fronts", &Options::extend_tail_fronts, 0, true }, { "mem_cap_mb", &Options::mem_cap_mb, 0, true },
-    { "pool_guard", &Options::pool_guard, 0, false },
+    { "pool_guard", &Options::pool_guard, 0, false }, { "pool_poison", &Options::pool_poison, 0, false },
 };
 static const OptionDef *find_option(const char *name) {
     for (const OptionDef &d : OPTION_TABLE) if (!strcmp(d.name, name)) return &d;
@@ -163,8 +163,8 @@ static void ensure_device() {
 // out-of-memory path without exhausting a 288 GB device.
 template <class T> struct DBuf {
     T *p = nullptr; size_t cap = 0;
-    void need(size_t n) {
-        if (n <= cap) return;
+    bool need(size_t n) {                                        // true: (re)allocated -- the contents are whatever the memory held before
+        if (n <= cap) return false;
         size_t c = std::max(n, cap + cap / 2);
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }       // (freed first: the front pool of a large graph must not exist twice)
         if (g_opt.mem_cap_mb > 0 && n * sizeof(T) > ((size_t)g_opt.mem_cap_mb << 20))
@@ -176,6 +176,7 @@ template <class T> struct DBuf {
             fail(e == hipErrorOutOfMemory ? ERR_OOM : ERR_HIP, "hipMalloc of %.1f MB failed: %s", (double)(c * sizeof(T)) / 1048576.0, hipGetErrorString(e));
         }
         cap = c;
+        return true;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };

@@ -119,7 +119,9 @@ struct Context {
     // dependency flags instead of on kernel boundaries (kernels.hip.h: wait_flag / publish_flag)
     int persist_l0 = -1;                  // first level of the multi-level launch, -1: none
     int p_up_off = 0, p_up_n = 0, p_dn_off = 0, p_dn_n = 0, p_nt = 1024; size_t p_up_lds = 0, p_dn_lds = 0; long long p_up_full = 0; int p_dn_maxns = 0;
-    DBuf<int> d_flags, d_flevel, d_perm, d_epoch;        // d_epoch: the iteration counter the batch path's dependency flags carry (kernels.hip.h wait_flag)
+    DBuf<int> d_flags, d_flevel, d_perm, d_epoch, d_marks;   // d_epoch: the step counter every dependency flag carries (kernels.hip.h wait_flag); d_marks: fronts regenerated by an incremental step
+    int flag_stride = 0;                  // d_flags = three arrays of this many words: "factor done", "x done", "vectors ready" per front
+    long long epoch_steps = 0;            // numeric phases enqueued since the counter was (re)started (rewind_epoch)
     DBuf<double> d_dinv, d_bsb_far; DBuf<int> d_bsb_flags;   // inverse diagonal blocks of the big fronts; scratch of k_backsolve_blk
     DBuf<int> d_solve_tab; std::vector<int> solve_tab;      // april_graph_cholesky_inc_solver: front lists of its back substitution
     DBuf<UpdRec> d_upd; DBuf<double> d_wbuf;               // incremental steps: update records per launch-list entry, the step's travelling vectors
@@ -164,7 +166,7 @@ struct Context {
     void release() {
         d_i32.release(); d_fd.release(); d_dest.release(); d_child.release(); d_lambda.release(); d_tab.release(); d_swap.release(); d_pos.release();
         d_pool.release(); d_H.release(); d_x.release(); d_diag.release(); d_bad.release(); h_bad.release(); patches.release();
-        h_done.release(); h_kstamp.release(); d_prof.release(); d_upd.release(); d_wbuf.release(); d_flags.release(); d_flevel.release(); d_epoch.release(); d_perm.release(); d_solve_tab.release(); d_dinv.release(); d_bsb_far.release(); d_bsb_flags.release(); d_guard.release(); d_guard_cnt.release(); n_guard = 0;
+        h_done.release(); h_kstamp.release(); d_prof.release(); d_upd.release(); d_wbuf.release(); d_flags.release(); d_flevel.release(); d_epoch.release(); d_marks.release(); d_perm.release(); d_solve_tab.release(); d_dinv.release(); d_bsb_far.release(); d_bsb_flags.release(); d_guard.release(); d_guard_cnt.release(); n_guard = 0;
         retire(gexec); retire(gexec_api); reap_retired(true);
         if (have_events) for (auto &e : ev) (void)hipEventDestroy(e);
         have_events = false;
@@ -251,6 +253,12 @@ template <class Fn> static int guarded_rc(const april_graph_cholesky_param_t *pa
     catch (const std::exception &e) { on_failure(param, g, ERR_INTERNAL, e.what()); return ERR_INTERNAL; }
 }
 
+// The step counter behind the dependency flags (kernels.hip.h wait_flag) starts here and is advanced once per numeric phase by the phase's
+// first kernel.  It is a 32-bit word: a context that has enqueued 2^30 phases (days of back-to-back iterations) starts it over, behind a
+// stream synchronisation and with every flag and mark zeroed again (rewind_epoch, called where phases are enqueued).
+static const int FIRST_EPOCH = 1 << 20;
+struct Context;
+static void rewind_epoch(Context &c, hipStream_t s, long long phases);
 // slack reserved at plan upload so that the incremental path can append without reallocating device buffers
 constexpr int INC_NODES = 4096, INC_FACT = 16384, INC_I32 = 4 << 20, INC_DEST = 1 << 20, INC_CHILD = 1 << 18, INC_TAB = 1 << 20;
 #define TAIL_POSES (g_opt.tail_poses)         // own poses per tail front of the incremental path (inc_fast_step), option tail_poses (>= 8)
@@ -489,7 +497,7 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     d.lambda = c.d_lambda.p;
     d.prof = nullptr; d.prof_mode = 0;
     d.schur_first_nub = std::max(0, g_opt.schur_first);
-    d.epoch = nullptr; d.flevel = nullptr; d.l0 = 0;           // (set in the copy the batch path's multi-level launches take: persist_plan)
+    d.epoch = nullptr; d.flevel = nullptr; d.l0 = 0; d.marks = nullptr;      // (epoch: below, once the counter exists; flevel / l0 / marks: set in the copies the multi-level launches take)
     if (getenv("APRILSAM_AMD_KPROF")) { c.d_prof.need((size_t)PROF_SLOTS * P.nF); HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)8 * PROF_SLOTS * P.nF, s)); d.prof = c.d_prof.p; d.prof_mode = atoi(getenv("APRILSAM_AMD_KPROF")) >= 2 ? atoi(getenv("APRILSAM_AMD_KPROF")) : 1; }
     c.d_swap.need((size_t)P.F + INC_FACT_); c.d_pos.need((size_t)P.N + INC_NODES_);
     fill_swap_host(c);
@@ -548,12 +556,18 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
     }
     // (dependency flags / front levels: also used by the extended-plan batch step, whose tail fronts get levels of their own)
     {
-        const int *before = c.d_flags.p;
-        c.d_flags.need((size_t)3 * (P.nF + MAX_TAIL_FRONTS)); c.d_flevel.need((size_t)P.nF + MAX_TAIL_FRONTS);      // done / x done / vectors ready
-        // The batch path never resets a flag: a finished front publishes the iteration number, which only grows (a flag that is read
-        // late or stale can then only mean "not yet").  New flag memory starts below every iteration number; the counter starts once per context.
-        if (c.d_flags.p != before) HIPCHECK(hipMemsetAsync(c.d_flags.p, 0, c.d_flags.cap * 4, s));
-        if (!c.d_epoch.p) { static const int first_epoch = 1 << 20; c.d_epoch.need(1); HIPCHECK(hipMemcpyAsync(c.d_epoch.p, &first_epoch, 4, hipMemcpyHostToDevice, s)); }
+        // No flag is ever reset: a finished front publishes the step number, which only grows (a flag that is read late or stale can then only
+        // mean "not yet").  New flag memory must therefore start BELOW every step number: zeroed whenever the buffer was (re)allocated --
+        // judged by DBuf::need itself, not by the pointer (hipFree + hipMalloc may hand the same address back for the larger block: round-5
+        // advisor finding) -- and the counter starts once per context, far above zero.
+        const size_t stride = (size_t)P.nF + MAX_TAIL_FRONTS;
+        const bool fresh = c.d_flags.need(3 * stride);            // done / x done / vectors ready
+        c.d_flevel.need(stride);
+        if (fresh || (size_t)c.flag_stride != stride) HIPCHECK(hipMemsetAsync(c.d_flags.p, 0, c.d_flags.cap * 4, s));
+        c.flag_stride = (int)stride;
+        if (c.d_marks.need(stride)) HIPCHECK(hipMemsetAsync(c.d_marks.p, 0, c.d_marks.cap * 4, s));
+        if (c.d_epoch.need(1)) { HIPCHECK(hipMemcpyAsync(c.d_epoch.p, &FIRST_EPOCH, 4, hipMemcpyHostToDevice, s)); c.epoch_steps = 0; }
+        d.epoch = c.d_epoch.p;
     }
     if (inc) { c.d_upd.need((size_t)g_opt.persist_max_fronts + 64); c.d_wbuf.need((size_t)1 << 19); }
     HIPCHECK(hipMemcpyAsync(c.d_flevel.p, P.f_level.data(), (size_t)P.nF * 4, hipMemcpyHostToDevice, s));
@@ -650,7 +664,23 @@ static void launch_backsolve(Context &c, const LevelPlan &L, hipStream_t s, Tic 
 // k_front_small with the configured workgroup size (option small_threads: 256 / 512 / 1024)
 // the multi-level launch of the factorisation: every small front of levels >= persist_l0
 // the plan as the batch path's two multi-level launches see it: flags carry the iteration number
-static DevPlan persist_plan(const Context &c) { DevPlan d = c.dp; d.epoch = c.d_epoch.p; d.flevel = c.d_flevel.p; d.l0 = c.persist_l0; return d; }
+static DevPlan persist_plan(const Context &c) { DevPlan d = c.dp; d.flevel = c.d_flevel.p; d.l0 = c.persist_l0; return d; }
+static void rewind_epoch(Context &c, hipStream_t s, long long phases) {
+    c.epoch_steps += phases;
+    if (c.epoch_steps < (1ll << 30) || !c.d_epoch.p) return;
+    HIPCHECK(hipStreamSynchronize(s));                      // nothing in flight reads a flag
+    HIPCHECK(hipMemsetAsync(c.d_flags.p, 0, c.d_flags.cap * 4, s));
+    HIPCHECK(hipMemsetAsync(c.d_marks.p, 0, c.d_marks.cap * 4, s));
+    HIPCHECK(hipMemcpyAsync(c.d_epoch.p, &FIRST_EPOCH, 4, hipMemcpyHostToDevice, s));
+    c.epoch_steps = phases;
+}
+// debug option pool_poison (kernels.hip.h k_poison): NaN into everything the step's launches hand from one workgroup to another
+static void enqueue_poison(Context &c, hipStream_t s, const int *list, int n, int what = 3, const UpdRec *recs = nullptr) {
+    if (g_opt.pool_poison <= 0 || n <= 0) return;
+    static_assert(offsetof(UpdRec, mode) % 4 == 0 && sizeof(UpdRec) % 4 == 0, "UpdRec::mode as a strided int");
+    hipLaunchKernelGGL(k_poison, dim3(n), dim3(TPB), 0, s, c.dp, list, n, recs ? (const int *)((const char *)recs + offsetof(UpdRec, mode)) : (const int *)nullptr,
+                       (int)(sizeof(UpdRec) / 4), what, c.d_pool.p, c.d_x.p);
+}
 static void launch_front_persist(Context &c, hipStream_t s) {
     const int *list = c.d_tab.p + c.p_up_off;
     int *fl = c.d_flags.p;
@@ -736,15 +766,14 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     if (ev) HIPCHECK(hipEventRecord(ev[0], s));
     if (c.dp.prof) HIPCHECK(hipMemsetAsync(c.d_prof.p, 0, (size_t)8 * PROF_SLOTS * P.nF, s));
     if (io_host) hipLaunchKernelGGL(k_load_states, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.d_state.p, gp.d_lp.p);
+    enqueue_poison(c, s, nullptr, P.nF);
     tic(K_LINEARIZE);
     if (F >= g_opt.linearize_staged_min)
         hipLaunchKernelGGL((k_linearize_t<true>), dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, unary_at_lp ? gp.d_upt.p : (const double *)nullptr,
-                           P.nF, c.d_flevel.p, 0, (int *)nullptr, c.persist_l0 >= 0 ? c.d_epoch.p : (int *)nullptr);
+                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, unary_at_lp ? gp.d_upt.p : (const double *)nullptr, c.d_epoch.p);
     else
         hipLaunchKernelGGL((k_linearize_t<false>), dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, unary_at_lp ? gp.d_upt.p : (const double *)nullptr,
-                           P.nF, c.d_flevel.p, 0, (int *)nullptr, c.persist_l0 >= 0 ? c.d_epoch.p : (int *)nullptr);
+                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, unary_at_lp ? gp.d_upt.p : (const double *)nullptr, c.d_epoch.p);
     if (!gp.host_idx.empty()) {         // host-evaluated factors: their blocks replace the null contributions written above
         const int nh = (int)gp.host_idx.size();
         HIPCHECK(hipMemcpyAsync(gp.d_hostH.p, gp.h_hostH.p, (size_t)33 * 8 * nh, hipMemcpyHostToDevice, s));
@@ -765,9 +794,9 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
         UpdArgs u = upd; if (l0 == 0) u.bad_out = io_host ? c.h_bad.p : nullptr;
         tic(K_BACKSOLVE);
         if (g_opt.wave_backsolve && c.p_dn_maxns <= BSW_MAX_NS)
-            hipLaunchKernelGGL(k_backsolve_w, dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, persist_plan(c), c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, c.d_flags.p + P.nF, c.d_bad.p, u);
+            hipLaunchKernelGGL(k_backsolve_w, dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, persist_plan(c), c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, c.d_flags.p + c.flag_stride, c.d_bad.p, u);
         else
-            hipLaunchKernelGGL((k_backsolve_t<true>), dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, persist_plan(c), c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + P.nF, 1, c.d_bad.p, u);
+            hipLaunchKernelGGL((k_backsolve_t<true>), dim3(c.p_dn_n), dim3(TPB), c.p_dn_lds, s, persist_plan(c), c.d_tab.p + c.p_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + c.flag_stride, 1, c.d_bad.p, u);
         toc();
     }
     for (int l = l0 - 1; l >= 0; l--) {
@@ -797,6 +826,7 @@ static void collect_kernel_times(Context &c) {
 static void run_numeric(Context &c, GraphPack &gp, bool timing, bool unary_at_lp = false, bool io_host = false, bool relin = false) {
     hipStream_t s = gp.stream;
     set_small_attr();
+    rewind_epoch(c, s, 1);
     if (timing && !c.have_events) { for (auto &e : c.ev) HIPCHECK(hipEventCreate(&e)); c.have_events = true; }
     if (io_host) {
         if (g_opt.use_graph && !timing && gp.host_idx.empty()) {

@@ -179,7 +179,8 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             }
             gp.h_out.need((size_t)3 * N);
             const UpdArgs upd1{ c.d_perm.p, gp.d_lp.p, nullptr, gp.d_dx.p, gp.h_out.p, gp.h_dx.p, c.h_bad.p };
-            const IncFlags nofl{ nullptr, 0, nullptr, 0, nullptr, 0 };
+            const IncFlags nofl{ c.d_epoch.p, nullptr, nullptr, 0 };          // (one workgroup, no flags: the step counter advances all the same)
+            rewind_epoch(c, s, 1);
             const int *dn = c.d_tab.p + I.tab_used; const int n_dn = solve_here ? 0 : (int)lst.size();
             const int one_nt = g_opt.inc_one_threads >= 1024 ? 1024 : g_opt.inc_one_threads >= 512 ? 512 : 256;
             if (one_nt >= 1024) hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), lds, s, pro, nofl, c.inl, c.dp, tstep, (const int *)nullptr, 0, dn, n_dn, c.d_pool.p, 0ll, c.d_x.p, upd1);
@@ -560,7 +561,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             mp = L.n_big == 0 && L.bs_gemv.grid == 0 && L.small_nt == mp_nt && L.n_small == L.n_all;
             mp_n += L.n_all;
         }
-        mp = mp && mp_n <= g_opt.persist_max_fronts && (size_t)2 * nFr <= c.d_flags.cap;
+        mp = mp && mp_n <= g_opt.persist_max_fronts && nFr <= c.flag_stride;
     }
     if (mp) {
         const int sh = (int)I.tab_used;
@@ -601,7 +602,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     }
     // updated fronts only exist inside that launch (or k_inc_one's loop over the same list): one record per list entry
     if (any_upd) {
-        if (!iu || (size_t)iu_n > c.d_upd.cap || (size_t)3 * nFr > c.d_flags.cap) return inc_fail(13);      // (the eligibility pass checked what iu checks: a full re-plan otherwise)
+        if (!iu || (size_t)iu_n > c.d_upd.cap || nFr > c.flag_stride) return inc_fail(13);      // (the eligibility pass checked what iu checks: a full re-plan otherwise)
         I.st_upd.resize(iu_n);
         const int sh = (int)I.tab_used;
         for (int i = 0; i < iu_n; i++) {
@@ -708,13 +709,20 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     const double tsub4 = now_ms();
     // ---- 5. numeric: new factors linearised, dirty fronts level by level, back substitution, update ----------------------
     set_small_attr();
-    const UpdCtx uctx = any_upd ? UpdCtx{ c.d_upd.p, c.d_wbuf.p, c.d_flags.p + (size_t)2 * nFr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p, gp.d_lp.p, gp.d_state.p } : UpdCtx{};
+    if (iu && nFr > c.flag_stride) return inc_fail(13);
+    rewind_epoch(c, s, 1);
+    // the plan as this step's multi-level launches see it: the flags carry the step number (advanced by the step's first kernel) -- dpi: a
+    // front waits for the children this step regenerates (marks, written by the prologue); dpm: a batch step on the extended plan, levels >= 1
+    DevPlan dpi = c.dp; dpi.marks = c.d_marks.p;
+    DevPlan dpm = c.dp; dpm.flevel = c.d_flevel.p; dpm.l0 = 1;
+    int *const xfl = c.d_flags.p + c.flag_stride;
+    const UpdCtx uctx = any_upd ? UpdCtx{ c.d_upd.p, c.d_wbuf.p, c.d_flags.p + (size_t)2 * c.flag_stride, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p, gp.d_lp.p, gp.d_state.p } : UpdCtx{};
     if (batch) {
         PL.launch(s);
+        enqueue_poison(c, s, nullptr, nFr);                // (debug option pool_poison: every front is re-factorised by a batch step)
         hipLaunchKernelGGL(k_load_states, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.d_state.p, gp.d_lp.p);      // l_point <- state
         hipLaunchKernelGGL((k_linearize_t<false>), dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, (const double *)nullptr,
-                           nFr, c.d_flevel.p, 1, mp ? c.d_flags.p : (int *)nullptr);
+                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, (const double *)nullptr, c.d_epoch.p);
     } else {
         // states first (the new factors are linearised at them; new priors at the node's current state) -- as patches of the few
         // poses whose host objects differ from the pinned mirror (pack_states_diff), or, when that is not known to be enough,
@@ -735,7 +743,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         pro.inl = g_opt.inc_inline && PL.hdr.size() <= (size_t)INL_PATCHES && PL.used <= (size_t)INL_BYTES;
         if (pro.inl) { memcpy(c.inl.hdr, PL.hdr.data(), PL.hdr.size() * sizeof(Patch)); memcpy(c.inl.pay, PL.buf.p, PL.used); }
         c.one_wait = 0;
-        const IncFlags fl = (!one && (iu || id)) ? IncFlags{ c.d_flags.p, nFr, c.d_tab.p + iu_off, iu ? iu_n : 0, c.d_tab.p + id_off, id ? id_n : 0 } : IncFlags{ nullptr, 0, nullptr, 0, nullptr, 0 };
+        const IncFlags fl = (!one && iu) ? IncFlags{ c.d_epoch.p, c.d_marks.p, c.d_tab.p + iu_off, iu_n } : IncFlags{ c.d_epoch.p, nullptr, nullptr, 0 };
         if (tail_fast && !one) {                       // the refactorisation in the prologue's launch, the back substitution in launches of its own
             hipLaunchKernelGGL(k_inc_one<1024>, dim3(1), dim3(1024), tail_refactor_lds(), s, pro, fl, c.inl, c.dp, tstep, (const int *)nullptr, 0, (const int *)nullptr, 0,
                                c.d_pool.p, iu_full, c.d_x.p, UpdArgs{});
@@ -754,20 +762,24 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         } else
             hipLaunchKernelGGL(k_inc_prologue, dim3(1), dim3(1024), 0, s, pro, fl, c.inl);
     }
+    if (g_opt.pool_poison > 0 && !batch && !one) {       // debug: what this step's multi-level launches hand over (the lists and descriptors arrived with the prologue's patches)
+        if (iu) { enqueue_poison(c, s, c.d_tab.p + iu_off, iu_n, 1, any_upd ? c.d_upd.p : nullptr); if (any_upd) HIPCHECK(hipMemsetAsync(c.d_wbuf.p, 0xff, c.d_wbuf.cap * 8, s)); }
+        if (id) enqueue_poison(c, s, c.d_tab.p + id_off, id_n, 2);
+    }
     if (iu && !one) {
         const int *list = c.d_tab.p + iu_off;
-        if (iu_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(iu_n), dim3(1024), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, c.d_flags.p, 1, uctx);
-        else if (iu_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(iu_n), dim3(512), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, c.d_flags.p, 1, uctx);
-        else hipLaunchKernelGGL(k_front_small<256>, dim3(iu_n), dim3(256), iu_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, c.d_flags.p, 1, uctx);
+        if (iu_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(iu_n), dim3(1024), iu_lds, s, dpi, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, c.d_flags.p, 1, uctx);
+        else if (iu_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(iu_n), dim3(512), iu_lds, s, dpi, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, c.d_flags.p, 1, uctx);
+        else hipLaunchKernelGGL(k_front_small<256>, dim3(iu_n), dim3(256), iu_lds, s, dpi, list, c.d_pool.p, c.d_H.p, c.d_bad.p, iu_full, c.d_flags.p, 1, uctx);
     }
     for (int l = 0; l < nLev; l++) {
         if (lev_dirty[l].empty() || iu || one) continue;
         if (mp && l >= 1) {
             if (l > 1) continue;
             const int *list = c.d_tab.p + mp_up_off;
-            if (mp_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(mp_n), dim3(1024), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, c.d_flags.p, 1);
-            else if (mp_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(mp_n), dim3(512), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, c.d_flags.p, 1);
-            else hipLaunchKernelGGL(k_front_small<256>, dim3(mp_n), dim3(256), mp_up_lds, s, c.dp, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, c.d_flags.p, 1);
+            if (mp_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(mp_n), dim3(1024), mp_up_lds, s, dpm, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, c.d_flags.p, 1);
+            else if (mp_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(mp_n), dim3(512), mp_up_lds, s, dpm, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, c.d_flags.p, 1);
+            else hipLaunchKernelGGL(k_front_small<256>, dim3(mp_n), dim3(256), mp_up_lds, s, dpm, list, c.d_pool.p, c.d_H.p, c.d_bad.p, mp_full, c.d_flags.p, 1);
             continue;
         }
         const LevelPlan &L = dl[l];
@@ -778,8 +790,8 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
             enqueue_big_steps(c, L, s, [](int) {}, []() {});
         }
     }
-    if (mp && g_opt.wave_backsolve && mp_dn_maxns <= BSW_MAX_NS) hipLaunchKernelGGL(k_backsolve_w, dim3(mp_n), dim3(TPB), mp_dn_lds, s, c.dp, c.d_tab.p + mp_dn_off, c.d_pool.p, c.d_x.p, c.d_flags.p + nFr, c.d_bad.p, UpdArgs{});
-    else if (mp) hipLaunchKernelGGL((k_backsolve_t<true>), dim3(mp_n), dim3(TPB), mp_dn_lds, s, c.dp, c.d_tab.p + mp_dn_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + nFr, 1, c.d_bad.p, UpdArgs{});
+    if (mp && g_opt.wave_backsolve && mp_dn_maxns <= BSW_MAX_NS) hipLaunchKernelGGL(k_backsolve_w, dim3(mp_n), dim3(TPB), mp_dn_lds, s, c.dp, c.d_tab.p + mp_dn_off, c.d_pool.p, c.d_x.p, xfl, c.d_bad.p, UpdArgs{});
+    else if (mp) hipLaunchKernelGGL((k_backsolve_t<true>), dim3(mp_n), dim3(TPB), mp_dn_lds, s, c.dp, c.d_tab.p + mp_dn_off, c.d_pool.p, c.d_x.p, 0, xfl, 1, c.d_bad.p, UpdArgs{});
     // incremental steps: the state update (state = l_point + dx, pinned mirrors of state / dx / failure record) rides on the
     // back substitution of the front that owns the pose -- every visited pose lives in a front of this sweep -- instead of
     // a launch of its own over all poses
@@ -789,8 +801,8 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
     const UpdArgs upd = batch ? UpdArgs{} : UpdArgs{ c.d_perm.p, gp.d_lp.p, nullptr, gp.d_dx.p, gp.h_out.p, gp.h_dx.p, c.h_bad.p };
     bool rode = one;
     if (id && !one) {
-        if (g_opt.wave_backsolve && id_maxns <= BSW_MAX_NS) hipLaunchKernelGGL(k_backsolve_w, dim3(id_n), dim3(TPB), id_lds, s, c.dp, c.d_tab.p + id_off, c.d_pool.p, c.d_x.p, c.d_flags.p + nFr, c.d_bad.p, upd);
-        else hipLaunchKernelGGL((k_backsolve_t<true>), dim3(id_n), dim3(TPB), id_lds, s, c.dp, c.d_tab.p + id_off, c.d_pool.p, c.d_x.p, 0, c.d_flags.p + nFr, 1, c.d_bad.p, upd);
+        if (g_opt.wave_backsolve && id_maxns <= BSW_MAX_NS) hipLaunchKernelGGL(k_backsolve_w, dim3(id_n), dim3(TPB), id_lds, s, c.dp, c.d_tab.p + id_off, c.d_pool.p, c.d_x.p, xfl, c.d_bad.p, upd);
+        else hipLaunchKernelGGL((k_backsolve_t<true>), dim3(id_n), dim3(TPB), id_lds, s, c.dp, c.d_tab.p + id_off, c.d_pool.p, c.d_x.p, 0, xfl, 1, c.d_bad.p, upd);
         rode = true;
     }
     for (int l = (one ? -1 : id ? (needed ? -1 : id_rest) : nLev - 1); l >= 0; l--) {

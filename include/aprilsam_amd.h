@@ -330,8 +330,9 @@ void aprilsam_amd_clear_error(void);
  *   "tail_poses"        own poses per tail front of the incremental path (default 28, at least 8)
  *   "persist"           1 (default): the top levels of the elimination tree -- as many as hold at most "persist_max_fronts"
  *                       (default 240) single-workgroup fronts -- run as ONE launch per sweep, fronts synchronised by
- *                       per-front dependency flags (round 5 found and fixed a release in these launches that did not wait for its L2
- *                       write-back -- a wrong result about once in 10^4 solves of chain-like graphs, profiles/r05_flag_soak.txt);
+ *                       per-front dependency flags that carry the step number and are never reset (round 5 found a release in these
+ *                       launches that did not wait for its L2 write-back -- a wrong result about once in 10^4 solves of chain-like graphs,
+ *                       profiles/r05_flag_soak.txt; the soak of the corrected build is profiles/r06_flag_soak.txt);
  *                       0 = one launch per level, no flags -- the conservative setting, M3500 then
  *                       costs about a quarter more per iteration (what the multi-level launches bought when they were introduced: 0.366 -> 0.294 ms)
  *   "blk_backsolve"     1 (default): multi-workgroup fronts are back-substituted 128 columns at a time by a chain
@@ -347,7 +348,12 @@ void aprilsam_amd_clear_error(void);
  *   "pool_guard"        debug, > 0: every frontal array of a plan is followed by a guard band of this many doubles (rounded up to 32), filled
  *                       with NaN when the plan is uploaded and checked after every synchronised step: a kernel that wrote into one ends the
  *                       call with error -16, a kernel that READ from one and used the value turns the results into NaN -- instead of a fault
- *                       that depends on where the allocation ends.  0 = off (default) */
+ *                       that depends on where the allocation ends.  0 = off (default)
+ *   "pool_poison"       debug, 1: before every step the UPDATE block of every front the step (re)factorises -- what its parent reads -- and the
+ *                       solution at its own positions -- what its children read -- are filled with NaN.  A dependency wait of a multi-level
+ *                       launch that passes early then produces NaN / "not positive definite" with certainty instead of the previous step's
+ *                       numbers (which are the right ones whenever the previous step solved the same system: the mask that hid round 5's
+ *                       release defect from everything but a soak).  Costs one extra pass over the fronts.  0 = off (default) */
 int aprilsam_amd_set_option(const char *name, double value);
 /* debug, with option "pool_guard" on and after a step on this param: points the guard check at a band inside a live frontal array; returns
  * -16 (the check works), -1 when the param has no guarded plan.  The param's cached plan is dropped, as after any failure */

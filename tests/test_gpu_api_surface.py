@@ -447,11 +447,17 @@ def test_bench_two_ranks_on_one_gpu_prints_one_valid_line(built):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
+    from tests.support.bench_line import check_line
+    out = check_line(r.stdout.splitlines()[-1], cpu_baseline=False)          # the LAST stdout line is what the driver parses
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "weak" and out["value"] > 0
     assert out["unit"] == "GN iterations/s" and out["roofline"]["frac"] > 0
-    l1 = out["lattice1m"]
-    assert "error" not in l1, l1
+    cfg = out["config"]
+    assert "lattice1m_error" not in cfg, cfg
+    assert cfg["lattice1m_n_gpus"] == 2 and cfg["lattice1m_ms_per_step"] > 0 and cfg["lattice1m_chi2_relerr_max"] < 1e-9
+    assert cfg["lattice1m_transport"].startswith("host callbacks") and cfg["lattice1m_comm_bytes_per_iteration"] > 0
+    # the nested record went to the side file
+    ex = json.load(open(os.path.join(ROOT, out["extras"])))
+    l1 = ex["lattice1m"]
     assert l1["n_gpus"] == 2 and "shards x2" in l1["parallelism"]
     assert max(l1["chi2_relerr_vs_reference"]) < 1e-9
-    assert out["multi_gpu"]["world"] == 2 and out["multi_gpu"]["transport"].startswith("host callbacks")
+    assert ex["multi_gpu"]["world"] == 2 and ex["multi_gpu"]["transport"].startswith("host callbacks")
