@@ -44,6 +44,7 @@ struct Options {
     int mem_cap_mb = 0;           // > 0: refuse any single device buffer above this size with ERR_OOM (tests: the out-of-memory path)
     int pool_guard = 0;           // debug: > 0 = every frontal array of a plan is followed by a guard band of this many doubles, NaN-filled at plan upload and checked after every synchronised step (ERR_GUARD); a stray read that is used poisons the result
     int pool_poison = 0;          // debug: 1 = before every step, the update block of every front the step (re)factorises and x at its own positions are filled with NaN: a dependency wait of a multi-level launch that passes early yields NaN instead of the previous step's numbers
+    int skip_flag_waits = 0;      // debug, negative control of pool_poison: 1 = the fronts of the batch path's multi-level factorisation launch do NOT wait for their children
     int panel_mode = 1;           // fronts too large for LDS whose own columns fit run in k_front_small's panel mode
 };
 extern Options g_opt;

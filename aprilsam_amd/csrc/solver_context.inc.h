@@ -684,7 +684,8 @@ static void enqueue_poison(Context &c, hipStream_t s, const int *list, int n, in
 static void launch_front_persist(Context &c, hipStream_t s) {
     const int *list = c.d_tab.p + c.p_up_off;
     int *fl = c.d_flags.p;
-    const DevPlan dpe = persist_plan(c);
+    DevPlan dpe = persist_plan(c);
+    if (g_opt.skip_flag_waits > 0) dpe.l0 = 1 << 30;       // debug (negative control of pool_poison): no front of this launch waits for its children
     if (c.p_nt >= 1024) hipLaunchKernelGGL(k_front_small<1024>, dim3(c.p_up_n), dim3(1024), c.p_up_lds, s, dpe, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, fl, 1);
     else if (c.p_nt >= 512) hipLaunchKernelGGL(k_front_small<512>, dim3(c.p_up_n), dim3(512), c.p_up_lds, s, dpe, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, fl, 1);
     else hipLaunchKernelGGL(k_front_small<256>, dim3(c.p_up_n), dim3(256), c.p_up_lds, s, dpe, list, c.d_pool.p, c.d_H.p, c.d_bad.p, c.p_up_full, fl, 1);

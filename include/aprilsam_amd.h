@@ -353,7 +353,9 @@ void aprilsam_amd_clear_error(void);
  *                       solution at its own positions -- what its children read -- are filled with NaN.  A dependency wait of a multi-level
  *                       launch that passes early then produces NaN / "not positive definite" with certainty instead of the previous step's
  *                       numbers (which are the right ones whenever the previous step solved the same system: the mask that hid round 5's
- *                       release defect from everything but a soak).  Costs one extra pass over the fronts.  0 = off (default) */
+ *                       release defect from everything but a soak).  Costs one extra pass over the fronts.  0 = off (default)
+ *   "skip_flag_waits"   debug, 1: the fronts of the batch path's multi-level factorisation launch do NOT wait for their children -- the negative
+ *                       control of "pool_poison" (the result must then come back NaN / not positive definite).  0 = off (default) */
 int aprilsam_amd_set_option(const char *name, double value);
 /* debug, with option "pool_guard" on and after a step on this param: points the guard check at a band inside a live frontal array; returns
  * -16 (the check works), -1 when the param has no guarded plan.  The param's cached plan is dropped, as after any failure */

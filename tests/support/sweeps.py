@@ -122,3 +122,34 @@ def soak(lib, seconds, seed, log=print, cases=None, focus=False):
                 f"re-run at once {'matches again' if again else 'STILL different: ' + str(c2.tolist())}")
         if time.time() - t_rep > 30: t_rep = time.time(); log(f"  {runs} runs, {bad} different, {time.time() - t0:.0f} s")
     return runs, bad
+
+
+# ---- the same graphs under the debug option pool_poison (NaN in everything a multi-level launch hands over) -----------------------
+def poison_soak(lib, rounds, calls, seed, log=print, cases=None):
+    """Every soak case `rounds` times in random order, fresh graph + param each time, `calls` april_graph_cholesky calls in a row (cold,
+    then warm -- the captured graph -- on states that keep changing), with option pool_poison on: before every call the update block of
+    every front and x are NaN-filled, so a dependency wait that passes early yields NaN / "not positive definite" with certainty instead
+    of the previous call's numbers.  Every chi^2 trace and final state is compared BITWISE with the first of its (case, options).
+    Returns (solves, differing runs)."""
+    rng = np.random.default_rng(seed)
+    cases = cases or soak_cases()
+    first = {}; solves = 0; bad = 0
+    order = [(ci, oi) for ci in range(len(cases)) for oi in (0, 3, 4)] * rounds
+    rng.shuffle(order)
+    for ci, oi in order:
+        label, arr = cases[ci]; o = dict(SOAK_OPTIONS[oi], pool_poison=1)
+        with lib.options(**o):
+            g = lib.new_graph(); g.build_from_arrays(*arr); p = lib.new_param()
+            chi2 = [g.chi2()]; spd = 0
+            for _ in range(calls):
+                g.cholesky(p); s = p.stats(); spd += s["not_spd"]
+                assert s["error_code"] == 0, (label, o, s)
+            chi2.append(g.chi2()); st = g.states(); p.destroy(); g.destroy()
+        solves += calls
+        key = (ci, oi); c = np.array(chi2)
+        if spd or not np.all(np.isfinite(st)) or not np.all(np.isfinite(c)):
+            bad += 1; log(f"POISON SEEN: {label} {o}: not_spd {spd} chi2 {c.tolist()} finite states {bool(np.all(np.isfinite(st)))}"); continue
+        if key not in first: first[key] = (c, st); continue
+        if not (np.array_equal(c, first[key][0]) and np.array_equal(st, first[key][1])):
+            bad += 1; log(f"DIFFERENT: {label} {o}: chi2 {c.tolist()} expected {first[key][0].tolist()} max state diff {float(np.max(np.abs(st - first[key][1]))):.3e}")
+    return solves, bad

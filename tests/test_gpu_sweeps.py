@@ -49,6 +49,52 @@ def test_soak_slice_every_result_bitwise_equal_to_the_first_of_its_case(lib):
     assert runs > 50 and bad == 0, lines
 
 
+def test_poisoned_hand_overs_never_reach_a_result(lib, oracle):
+    """Debug option pool_poison: before every step the update block of every front (what a parent's extend-add reads) and x (what a child's
+    back substitution gathers) are NaN-filled.  A dependency wait of a multi-level launch that passes early -- round 5's release defect,
+    about one solve in 10^4 on chain-like graphs, invisible to every test because the stale numbers were the previous run's correct ones --
+    then produces NaN or "not positive definite" with certainty.  The 14 soak cases x 3 option sets x 3 rounds, 16 calls each (a cold call,
+    then the captured graph on states that keep changing): 2 016 solves, none may show a NaN, all bitwise equal to the first of their case;
+    and the numbers are the unpoisoned ones (oracle, two iterations)."""
+    lines = []
+    solves, bad = sweeps.poison_soak(lib, 3, 16, 5, log=lines.append)
+    assert solves >= 2000 and bad == 0, lines
+    cases = sweeps.soak_cases()
+    with lib.options(pool_poison=1):
+        sweeps.sweep_batch(lib, oracle, [cases[0], cases[7], cases[9]], (dict(), dict(small_lds_kb=0)), 1e-6, 1e-5, log=lambda s: None)
+
+
+def test_the_poison_is_seen_when_a_wait_is_skipped(lib):
+    """... and the negative control: the poison does reach the result when a hand-over IS read early.  persist = 1 with the dependency
+    waits of the multi-level launches switched off (debug option skip_flag_waits): a chain-like graph must come back NaN / not positive
+    definite / with a dependency time-out -- if it does not, pool_poison poisons nothing the launches read."""
+    arr = sweeps.soak_cases()[0][1]
+    seen = 0
+    with lib.options(pool_poison=1, skip_flag_waits=1):
+        for _ in range(3):
+            g = lib.new_graph(); g.build_from_arrays(*arr); p = lib.new_param()
+            g.cholesky(p); s = p.stats(); st = g.states(); c = g.chi2()
+            seen += int(s["not_spd"] != 0 or s["error_code"] != 0 or not np.all(np.isfinite(st)) or not np.isfinite(c))
+            lib.clear_error(); p.destroy(); g.destroy()
+    assert seen >= 1
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(inc_one=0, inc_tail=0), dict(inc_update=0, inc_one=0)], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()) or "default")
+def test_incremental_demo_under_pool_poison(lib, opts):
+    """the incremental path's multi-level launches (regenerated fronts, low-rank updates, the partial back substitution) with everything
+    they hand over poisoned first: the first 700 poses of the M3500 demo keep the reference's fall-back schedule and chi^2 trace"""
+    import os
+    from aprilsam_amd import datasets, harness
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "m3500_inc_demo.npz"))
+    n = 700
+    with lib.options(pool_poison=1, **opts):
+        res = harness.run_demo(lib, datasets.m3500_arrays(), max_poses=n, deterministic=True)
+    assert np.all(np.isfinite(res["chi2"])) and np.all(np.isfinite(res["final_states"]))
+    assert np.array_equal(res["was_batch"], G["was_batch"][:n])
+    rel = np.abs(res["chi2"] - G["chi2"][:n]) / np.maximum(G["chi2"][:n], 1e-9)
+    assert np.max(rel) < 1e-6, (int(np.argmax(rel)), float(np.max(rel)))
+
+
 def test_odd_lattices(lib, oracle):
     sweeps.sweep_batch(lib, oracle, [(f"lattice K={K}", lib.lattice_arrays(K)) for K in (37, 91)],
                        (dict(), dict(small_lds_kb=0), dict(small_lds_kb=48, leaf_nodes=24), dict(small_lds_kb=0, leaf_nodes=7, syrk_xcd_order=1, syrk_small_tiles=1 << 30),
