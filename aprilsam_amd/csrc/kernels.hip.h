@@ -2692,11 +2692,15 @@ __device__ __forceinline__ void inc_prologue_body(const IncPrologue &a, const In
     // dependency flags of the step's two multi-level launches: nothing is reset -- the step counter advances, a finished front publishes the
     // new number, and the fronts this step regenerates are marked with it (a parent waits for exactly those children; the factors of the
     // others are older and complete)
-    __shared__ int s_ev;
-    if (fl.epoch && threadIdx.x == 0) s_ev = atomicAdd(fl.epoch, 1) + 1;
+    // (no static LDS here: the callers' dynamic LDS goes up to the 160 KB limit.  Thread 0's atomic has RETURNED -- it is performed in the L2 --
+    // before the barrier; everybody reads the new number from there afterwards)
+    if (fl.epoch && threadIdx.x == 0) { const int old = atomicAdd(fl.epoch, 1); asm volatile("s_waitcnt vmcnt(0)" :: "v"(old) : "memory"); }
     __syncthreads();                                    // (also: the patches above carry the list read below)
     if (a.stamps && threadIdx.x == 0) a.stamps[1] = wall_clock64();
-    if (fl.marks) for (int i = threadIdx.x; i < fl.n_up; i += nthr) reset_flag(fl.marks + fl.up_list[i], s_ev);
+    if (fl.marks && (int)threadIdx.x < fl.n_up) {
+        const int ev = __hip_atomic_load(fl.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = threadIdx.x; i < fl.n_up; i += nthr) reset_flag(fl.marks + fl.up_list[i], ev);
+    }
     if (f_end - f_begin > TAIL_MAXF) mirror = nullptr;
     for (int g0 = 0; g0 < f_end - f_begin; g0 += nthr)
         linearise_factor<false>(g0 + (int)threadIdx.x, f_begin, f_end, nullptr, fa, fb, Z, Wm, lp, st, swp, slot_blk, slot_rhs, Hc, nullptr, nullptr, nullptr, mirror);
