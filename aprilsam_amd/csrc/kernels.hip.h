@@ -897,39 +897,54 @@ __device__ __forceinline__ void lds_panel_syrk(double *__restrict__ S, int ld, i
 
 // LDS -> LDS variant with 16 x 16 tiles: the fronts that live in LDS are a few tiles wide, so small tiles spread the
 // update over all waves (the FP64 MFMA pipe of a SIMD, 64 cycles per instruction, is the limit here) and waste less
-// above the diagonal.  All operands of a tile are requested before the first MFMA (K <= 16: two LDS round trips).
+// above the diagonal.  K = k_hi - k_lo <= 16 (one 16-column block of the factorisation).
+// Round 6: a tile of this routine was 3 000 cycles -- four dependent MFMAs and twelve LDS accesses -- because the tile index lived in a
+// VGPR (the decode of the trapezoid ran per lane, in loops under exec masks), the K loop was not unrolled (two LDS round trips per
+// MFMA) and the four result stores were four branches (tools/ubench/front_factor.hip: 2 900-3 450 cycles for the next block's update on
+// a front of 123 rows, and far updates that outlasted the pivot chain they were meant to hide behind).  Now the tile index is a scalar
+// (decoded by a few SALU instructions; one tile column when the update covers a single block), all twelve loads of a tile are issued
+// before the first MFMA, the K steps are unrolled behind wave-uniform branches, and the stores are predicated.  Same operands, same
+// accumulation order: bit-identical results.
 template <int NT>
 __device__ __forceinline__ void lds_syrk16(double *__restrict__ S, int ld, int k_lo, int k_hi, int col_lo, int col_hi, int Rv,
                                            int w0 = 0, int nw = NT / 64) {          // tiles go round-robin over waves [w0, w0 + nw)
-    const int wave = (threadIdx.x >> 6) - w0, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - w0;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
     if (wave < 0 || wave >= nw) return;
-    const int ntr = (Rv - col_lo + 15) / 16, ntc = (col_hi - col_lo + 15) / 16;
+    const int ntr = (Rv - col_lo + 15) >> 4, ntc = (col_hi - col_lo + 15) >> 4;
     const int ntiles = ntc * ntr - ntc * (ntc - 1) / 2;
-    const int kw = k_hi - k_lo, nk = (kw + 3) >> 2;
+    const int kw = k_hi - k_lo, nk = (kw + 3) >> 2;                              // 1 <= nk <= 4
     for (int l = wave; l < ntiles; l += nw) {
-        int ti, tj;
-        trapezoid_tile(l, ntr, ntc, &ti, &tj);
+        int ti = l, tj = 0;                                                      // column-major lower trapezoid: column tj holds ntr - tj tiles
+        while (ti >= ntr - tj) { ti -= ntr - tj; tj++; }
+        ti += tj;
         const int i0 = col_lo + 16 * ti, j0 = col_lo + 16 * tj;
         const int rj = min(j0 + l15, Rv - 1), ri = min(i0 + l15, Rv - 1);
-        d4_t acc = (d4_t){ 0, 0, 0, 0 };
         // C elements of this lane: row i = i0 + l15, columns j = j0 + l4 + 4 * reg
-        const int i = i0 + l15;
-        int off[4];
+        const int i = i0 + l15, jb = j0 + l4;
+        const int cbase = jb * ld + i;
+        bool ok[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) { const int j = j0 + l4 + 4 * reg; off[reg] = (i < Rv && j < col_hi && i >= j) ? j * ld + i : -1; }
-        double cv[4];
+        for (int reg = 0; reg < 4; reg++) { const int j = jb + 4 * reg; ok[reg] = i < Rv && j < col_hi && i >= j; }
+        double cv[4], x[4], y[4];
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) cv[reg] = S[off[reg] >= 0 ? off[reg] : 0];
-#pragma unroll 4
-        for (int ks = 0; ks < nk; ks++) {
+        for (int reg = 0; reg < 4; reg++) cv[reg] = S[ok[reg] ? cbase + 4 * reg * ld : 0];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
             const int kk = 4 * ks + l4;
-            const bool kok = kk < kw;
-            const double *col = S + (size_t)(k_lo + (kok ? kk : 0)) * ld;
-            const double x = col[rj], y = col[ri];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kok ? x : 0.0, kok ? y : 0.0, acc, 0, 0, 0);
+            const double *col = S + (k_lo + (kk < kw ? kk : 0)) * ld;            // (clamped: always a valid address; masked below)
+            x[ks] = col[rj]; y[ks] = col[ri];
+        }
+        d4_t acc = (d4_t){ 0, 0, 0, 0 };
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            if (ks < nk) {                                                       // (wave-uniform)
+                const bool kok = 4 * ks + l4 < kw;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kok ? x[ks] : 0.0, kok ? y[ks] : 0.0, acc, 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) if (off[reg] >= 0) S[off[reg]] = cv[reg] - acc[reg];
+        for (int reg = 0; reg < 4; reg++) if (ok[reg]) S[cbase + 4 * reg * ld] = cv[reg] - acc[reg];
     }
 }
 
@@ -958,8 +973,12 @@ constexpr int GB = 4;
 constexpr int BW = 16;
 // one block step: columns [k0, k0 + wdt), wdt <= BWT, of the LDS array S; BWT = 16, or 8 for the short last block of a front
 // (a 2-column remainder should not pay for a 16-step chain)
+// Dd (out): the factored diagonal block as the wave that ran chunk 0 holds it -- lane r < BWT, Dd[c] = L[k0 + r][k0 + c] for c <= r (garbage
+// above the diagonal) -- for chain_store_diag AFTER the workgroup barrier that follows (other waves may still be loading their copy of
+// the block from the front).  Round 6: until then the block went through a staging area in LDS and a copy by 256 threads behind the
+// barrier -- 400 cycles on the critical path of every 16 columns (tools/ubench/front_factor.hip).
 template <int NT, int BWT>
-__device__ __forceinline__ void chain_block(double *S, int ld, int k0, int wdt, int Rv, int *bad, double *stage, int nwc) {
+__device__ __forceinline__ void chain_block(double *S, int ld, int k0, int wdt, int Rv, int *bad, double (&Dd)[BWT], int nwc) {
     constexpr int BROWS = 64 - BWT;      // BROWS: rows below the diagonal block per wave; the chunks go over the waves < nwc
     constexpr int PER = BWT <= 8 ? 1 : (BWT - 2 + 7) / 8;      // independent fmas behind each of the eight steps of the next pivot's 1/sqrt (2 at BWT = 16)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1019,7 +1038,7 @@ __device__ __forceinline__ void chain_block(double *S, int ld, int k0, int wdt, 
             }
             inv = y;
         }
-        // rows below the block go back to LDS now; the diagonal block itself goes through a staging area and reaches
+        // rows below the block go back to LDS now; the diagonal block itself stays in the registers of the wave that ran chunk 0 and reaches
         // the front only after the barrier (other waves may still be loading their copy of it).  Stores of a partial
         // block are redirected to column 0, whose own value comes last (no conditional stores).
         if (valid && !isdiag) {
@@ -1027,20 +1046,20 @@ __device__ __forceinline__ void chain_block(double *S, int ld, int k0, int wdt, 
             for (int c = BWT - 1; c >= 0; c--) S[(size_t)(k0 + (c < wdt ? c : 0)) * ld + row] = (c < wdt) ? D[c] : D[0];
         }
         if (ch == 0) {
-            if (isdiag) {
 #pragma unroll
-                for (int c = 0; c < BWT; c++) stage[c * BWT + lane] = (lane >= c) ? D[c] : 0.0;
-            }
+            for (int c = 0; c < BWT; c++) Dd[c] = D[c];
             if (isbad && lane == 0) { if (atomicCAS(bad, 0, 1) == 0) { bad[2] = 1; bad[3] = k0 / 3; } }
         }
     }
 }
-// after a workgroup barrier: the factored diagonal block goes from the staging area into the front
+// after a workgroup barrier, by the wave that ran chunk 0 of chain_block (wave 0 of the chain's waves): the factored diagonal block goes
+// from its registers into the front -- the lower triangle, and zeros above it (what the assembly left there anyway)
 template <int BWT>
-__device__ __forceinline__ void chain_finish(double *S, int ld, int k0, int wdt, const double *stage) {
-    if (threadIdx.x < BWT * BWT) {
-        const int c = threadIdx.x / BWT, r = threadIdx.x % BWT;
-        if (c < wdt && r < wdt) S[(size_t)(k0 + c) * ld + k0 + r] = stage[c * BWT + r];
+__device__ __forceinline__ void chain_store_diag(double *S, int ld, int k0, int wdt, const double (&Dd)[BWT]) {
+    const int r = threadIdx.x & 63;
+    if (r < wdt) {                                     // (one exec mask for the lot: the entries above the diagonal are stored as the zeros they are)
+#pragma unroll
+        for (int c = 0; c < BWT; c++) if (c < wdt) S[(k0 + c) * ld + k0 + r] = (c <= r) ? Dd[c] : 0.0;
     }
 }
 // Look-ahead inside the workgroup: after block k only the NEXT block's columns are updated by everybody; then the first
@@ -1050,18 +1069,20 @@ __device__ __forceinline__ void chain_finish(double *S, int ld, int k0, int wdt,
 // max(chain, far update) + the 16-column update instead of chain + full update.
 // scalar dimensions: ns columns to eliminate, Rv valid rows, columns < hi receive the trailing update
 template <int NT>
-__device__ __forceinline__ void factor_dense_blk(double *S, int ld, int ns, int Rv, int hi, int *bad, double *stage, long long *pf = nullptr) {
+__device__ __forceinline__ void factor_dense_blk(double *S, int ld, int ns, int Rv, int hi, int *bad, double * /*unused since round 6: the staging area*/, long long *pf = nullptr) {
     constexpr int NW = NT / 64;
     long long t_chain = 0, t_syrk = 0, t0 = 0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double Dd[BW];                                 // the diagonal block of the chain just run, in wave 0's registers (chain_block)
     auto chain = [&](int k0, int nwc) {
         const int wdt = min(BW, ns - k0);
-        if (wdt <= 8) chain_block<NT, 8>(S, ld, k0, wdt, Rv, bad, stage, nwc);
-        else chain_block<NT, 16>(S, ld, k0, wdt, Rv, bad, stage, nwc);
+        if (wdt <= 8) { double (&D8)[8] = reinterpret_cast<double (&)[8]>(Dd); chain_block<NT, 8>(S, ld, k0, wdt, Rv, bad, D8, nwc); }
+        else chain_block<NT, 16>(S, ld, k0, wdt, Rv, bad, Dd, nwc);
     };
-    auto finish = [&](int k0) {
+    auto finish = [&](int k0) {                    // (behind a barrier; one wave, a handful of LDS stores that nothing on the critical path waits for)
+        if (wave != 0) return;
         const int wdt = min(BW, ns - k0);
-        if (wdt <= 8) chain_finish<8>(S, ld, k0, wdt, stage); else chain_finish<16>(S, ld, k0, wdt, stage);
+        if (wdt <= 8) chain_store_diag<8>(S, ld, k0, wdt, reinterpret_cast<const double (&)[8]>(Dd)); else chain_store_diag<16>(S, ld, k0, wdt, Dd);
     };
     auto chain_waves = [&](int k0) {               // waves that get a chunk of rows of block k0's chain, at most half of them
         const int wdt = min(BW, ns - k0), brows = 64 - (wdt <= 8 ? 8 : 16);
@@ -1077,8 +1098,10 @@ __device__ __forceinline__ void factor_dense_blk(double *S, int ld, int ns, int 
         const int wdt = min(BW, ns - k0), below0 = k0 + wdt;
         if (below0 < ns) {
             const int next_hi = min(below0 + BW, ns), cw = chain_waves(below0);
-            lds_syrk16<NT>(S, ld, k0, below0, below0, next_hi, Rv);
-            __syncthreads();                                // (also orders the diagonal-block store of finish() before anybody reads it)
+            // the next block's columns, by every wave but the one that is still storing the diagonal block (when there are waves to spare)
+            if (NW >= 8) lds_syrk16<NT>(S, ld, k0, below0, below0, next_hi, Rv, 1, NW - 1);
+            else lds_syrk16<NT>(S, ld, k0, below0, below0, next_hi, Rv);
+            __syncthreads();
             if (pf) { const long long t1 = wall_clock64(); t_syrk += t1 - t0; t0 = t1; }
             if (wave < cw) {
                 long long w0_ = 0, c0_ = 0;
@@ -2755,7 +2778,7 @@ __device__ __forceinline__ void tail_refactor(const TailStep ts, double *__restr
     const int c0 = 3 * ts.a_idx, q = 3 * (nsb - ts.a_idx), qo = 3 * (ts.n_old - ts.a_idx);
     double *Fg = pool + ts.off;
     struct { int first; } D{ ts.first };
-    double *M = S, *Lt = S + TAILQ * TAIL_LD, *stage = Lt + TAILQ * TAIL_LD;
+    double *M = S, *Lt = S + TAILQ * TAIL_LD;
     const int nf = min(a.f_end - a.f_begin, TAIL_MAXF);
     int nas[TAIL_MAXF], nbs[TAIL_MAXF];                  // poses of the new factors (all loads in flight together, behind step 1's)
 #pragma unroll
@@ -2802,9 +2825,10 @@ __device__ __forceinline__ void tail_refactor(const TailStep ts, double *__restr
     //    (the chain runs all the steps of its width whatever q is: a new pose and its odometry factor are 6 columns, not 24)
     auto chain = [&](auto w_) {
         constexpr int W = decltype(w_)::value;
-        chain_block<NT, W>(M, TAIL_LD, 0, q, q + 1, a.bad, stage, 1);
+        double Dd[W];
+        chain_block<NT, W>(M, TAIL_LD, 0, q, q + 1, a.bad, Dd, 1);
         __syncthreads();
-        for (int e = tid; e < W * W; e += NT) { const int c = e / W, r = e - c * W; if (c < q && r < q) M[c * TAIL_LD + r] = stage[e]; }
+        if (tid < 64) chain_store_diag<W>(M, TAIL_LD, 0, q, Dd);
         __syncthreads();
     };
     if (q <= 8) chain(std::integral_constant<int, 8>{}); else if (q <= 16) chain(std::integral_constant<int, 16>{}); else chain(std::integral_constant<int, TAILQ>{});

@@ -32,6 +32,8 @@ struct Options {
     int tp_threads = 512;         // ... and on throughput levels (>= tp_fronts fronts)
     int tp_fronts = 1000;         // levels with at least this many fronts are "throughput levels" ...
     int tp_lds_kb = 64;           // ... where only fronts up to this LDS size run fully in LDS (the rest: panel mode, more workgroups per CU)
+    int amalg = 0;                // 1 = separator amalgamation (symbolic.cpp: amalgamate): separator fronts take in child separators where a cost model of the critical path (hand-over per front vs pivot chain per column) says so -- fewer dependent levels on graphs the size of M3500
+    int amalg_max = 64;           // ... as long as the merged front owns at most this many poses
     int pin_last = 0;             // nested dissection keeps the pin_last newest poses out of the dissection: they form the root front ("recent poses last")
     int batch_extend = 1;         // batch calls on a graph that only grew reuse the plan: appended poses become tail fronts, every front is re-factorised
     int extend_tail_fronts = 3;   // ... until the appended poses are this many tail fronts' worth, units of 24 poses (then: full re-plan).  Measured, round 4: demo --batch_update_only 1 500 poses 481 / 388 / 372 / 371 ms at 8 / 4 / 3 / 2; the incremental demo does not care (510 +- 3 %)

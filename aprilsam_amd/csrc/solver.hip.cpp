@@ -71,7 +71,7 @@ static const OptionDef OPTION_TABLE[] = {
     { "persist_max_fronts", &Options::persist_max_fronts, 0, false }, { "linearize_staged_min", &Options::linearize_staged_min, 0, false },
     { "wave_backsolve", &Options::wave_backsolve, 0, false }, { "blk_backsolve", &Options::blk_backsolve, 0, false }, { "tail_poses", &Options::tail_poses, 8, false },
     { "batch_extend", &Options::batch_extend, 0, true }, { "extend_tail_fronts", &Options::extend_tail_fronts, 0, true }, { "mem_cap_mb", &Options::mem_cap_mb, 0, true },
-    { "pool_guard", &Options::pool_guard, 0, false }, { "pool_poison", &Options::pool_poison, 0, false }, { "skip_flag_waits", &Options::skip_flag_waits, 0, false },
+    { "pool_guard", &Options::pool_guard, 0, false }, { "amalg", &Options::amalg, 0, false }, { "amalg_max", &Options::amalg_max, 1, false }, { "pool_poison", &Options::pool_poison, 0, false }, { "skip_flag_waits", &Options::skip_flag_waits, 0, false },
 };
 static const OptionDef *find_option(const char *name) {
     for (const OptionDef &d : OPTION_TABLE) if (!strcmp(d.name, name)) return &d;

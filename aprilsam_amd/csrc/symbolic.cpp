@@ -21,6 +21,93 @@
 
 namespace asam {
 
+// Separator amalgamation (option amalg).  On a graph the size of M3500 nothing is bound by flops: the factorisation is a chain of
+// dependent fronts, and a front on that chain costs about HAND = 12 us of hand-over (flag, extend-add of the children's blocks from
+// memory, store + release of its update block) plus PERCOL = 0.19 us per own column (the in-register pivot chains;
+// profiles/r05_front_times_m3500.txt), the back substitution another 2.7 us + 0.8 us per 64 columns.  A separator front that takes in a
+// child SEPARATOR -- one dense front whose own part is the child separators first, then its own: a valid supernode, the blocks between two
+// child separators are structural zeros treated as dense -- removes one hand-over from the path for the price of the child's columns on the
+// parent's chain.  Bottom-up over the dissection tree with that model: cost(n) = hand + percol * own(n) + max over children cost(c); a node
+// tries to take in its 1, 2, ... most expensive separator children (they sit on its critical path; a taken child brings the separators it
+// took in itself, and its remaining children become n's) and keeps the prefix with the lowest cost(n), as long as the merged front still
+// fits the single-workgroup kernel in panel mode (own columns x all rows in LDS; rows = own + the region's boundary, counted here) and owns
+// at most amalg_max poses.  Leaves are never merged: they hold most of the poses and run side by side.  M3500: 9 levels -> 5-6.
+static void amalgamate(NDTree &tree, int N, const std::vector<int> &ap, const std::vector<int> &ai, int max_own, size_t lds_budget) {
+    const double HAND = 12.0 + 2.7, PERCOL = 0.19 + 0.8 / 64.0;         // us, up-sweep + down-sweep
+    constexpr int REGION_MAX = 4096;                                      // subtrees with more poses are not looked at (their separators are far too wide to merge)
+    const int nT = (int)tree.nodes.size();
+    // post-order
+    std::vector<int> order; order.reserve(nT);
+    {
+        std::vector<std::pair<int, size_t>> st;
+        for (int r : tree.roots) {
+            st.push_back({ r, 0 });
+            while (!st.empty()) {
+                auto &top = st.back();
+                const NDTree::Node &nd = tree.nodes[top.first];
+                if (top.second < nd.children.size()) { const int c = nd.children[top.second++]; st.push_back({ c, 0 }); continue; }
+                order.push_back(top.first); st.pop_back();
+            }
+        }
+    }
+    std::vector<int> region(nT, 0);                                       // poses in the subtree
+    for (int n : order) { region[n] = (int)tree.nodes[n].verts.size(); for (int c : tree.nodes[n].children) region[n] += region[c]; }
+    // boundary of a subtree's region = update rows of its top front (the region is eliminated completely below it)
+    std::vector<int> stamp_in(N, -1), stamp_b(N, -1), bnd(nT, -1);
+    std::vector<int> stk, verts;
+    auto boundary = [&](int n) {
+        verts.clear(); stk.assign(1, n);
+        while (!stk.empty()) { const int k = stk.back(); stk.pop_back(); for (int v : tree.nodes[k].verts) { stamp_in[v] = n; verts.push_back(v); } for (int c : tree.nodes[k].children) stk.push_back(c); }
+        int cnt = 0;
+        for (int v : verts) for (int e = ap[v]; e < ap[v + 1]; e++) { const int u = ai[e]; if (stamp_in[u] != n && stamp_b[u] != n) { stamp_b[u] = n; cnt++; } }
+        return cnt;
+    };
+    std::vector<double> cost(nT, 0.0);
+    std::vector<char> dead(nT, 0);
+    for (int n : order) {
+        NDTree::Node &nd = tree.nodes[n];
+        auto eval = [&](size_t own, const std::vector<int> &kids) { double m = 0; for (int c : kids) m = std::max(m, cost[c]); return HAND + PERCOL * 3.0 * (double)own + m; };
+        cost[n] = eval(nd.verts.size(), nd.children);
+        if (nd.children.empty() || region[n] > REGION_MAX) continue;
+        std::vector<int> seps;
+        for (int c : nd.children) if (!tree.nodes[c].children.empty()) seps.push_back(c);
+        if (seps.empty()) continue;
+        std::sort(seps.begin(), seps.end(), [&](int a, int b) { return cost[a] != cost[b] ? cost[a] > cost[b] : a < b; });
+        if (bnd[n] < 0) bnd[n] = boundary(n);
+        size_t own = nd.verts.size();
+        std::vector<int> kids = nd.children;
+        double best = cost[n]; size_t best_k = 0;
+        for (size_t k = 0; k < seps.size(); k++) {
+            const NDTree::Node &ch = tree.nodes[seps[k]];
+            own += ch.verts.size();
+            const size_t R = 3 * (own + (size_t)bnd[n] + 1);
+            if (own > (size_t)max_own || (R | 1) * 3 * own * 8 > lds_budget) break;
+            kids.erase(std::find(kids.begin(), kids.end(), seps[k]));
+            kids.insert(kids.end(), ch.children.begin(), ch.children.end());
+            const double cst = eval(own, kids);
+            if (cst < best - 1e-9) { best = cst; best_k = k + 1; }
+        }
+        if (!best_k) continue;
+        std::vector<int> vs;
+        for (size_t k = 0; k < best_k; k++) {
+            NDTree::Node &ch = tree.nodes[seps[k]];
+            vs.insert(vs.end(), ch.verts.begin(), ch.verts.end());
+            nd.children.erase(std::find(nd.children.begin(), nd.children.end(), seps[k]));
+            nd.children.insert(nd.children.end(), ch.children.begin(), ch.children.end());
+            dead[seps[k]] = 1; ch.verts.clear(); ch.children.clear();
+        }
+        vs.insert(vs.end(), nd.verts.begin(), nd.verts.end());
+        nd.verts.swap(vs);
+        cost[n] = best;
+    }
+    std::vector<int> remap(nT, -1);
+    int w = 0;
+    for (int i = 0; i < nT; i++) if (!dead[i]) { remap[i] = w; if (w != i) tree.nodes[w] = std::move(tree.nodes[i]); w++; }
+    tree.nodes.resize(w);
+    for (auto &nd : tree.nodes) for (int &c : nd.children) c = remap[c];
+    for (int &r : tree.roots) r = remap[r];
+}
+
 void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf_nodes) {
     // one plan at a time: the dissection and the symbolic phases share ONE pool of planner threads (ordering.cpp: PlanPool) -- calls
     // from threads that drive different devices queue up here, everything else they do runs side by side
@@ -77,6 +164,10 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
         tree.roots.assign(1, (int)tree.nodes.size() - 1);
     } else
         nested_dissection(N, ap, ai, xy, leaf_nodes, tree);
+    if (g_opt.amalg > 0) {          // (the LDS of a 16-wave workgroup's work lists comes off the budget: kernels.hip.h wl_bytes)
+        const size_t wl = 64 * 24 + 16 * (128 * 8 + 64 * 8);
+        amalgamate(tree, N, ap, ai, std::max(g_opt.amalg_max, 1), (size_t)std::max(g_opt.small_lds_kb, 32) * 1024 - wl);
+    }
     const int nT = (int)tree.nodes.size();
     P.nF = nT;
     P.perm.assign(N, -1); P.pos.assign(N, -1);
