@@ -659,7 +659,7 @@ __device__ __forceinline__ void assemble_front(const DevPlan &P, const FrontDesc
         c.rel_begin = __builtin_amdgcn_readfirstlane(c.rel_begin);
         return c;
     };
-    constexpr int TE = 4;                                                        // items per trip: 3 * TE column loads in flight per lane
+    constexpr int TE = 4;                                                        // items per trip: 3 * TE column loads in flight per lane (8 at 1024 threads, round 6: M3500 0.2129 -> 0.2268 ms)
     struct Trip { double v[3 * TE]; int d[TE], rc[TE], col[TE], cc[TE], nrow[TE], r0[TE]; };   // item = (child block, 64-row pass 0 or 1)
     auto load_trip = [&](int i, int n, Trip &T) {
         // three passes over the items so that the LDS reads of all of them (work-list entry, then child record) are in

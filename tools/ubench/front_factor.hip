@@ -56,13 +56,16 @@ __device__ __forceinline__ void old_lds_syrk16(double *__restrict__ S, int ld, i
 #endif
 // VAR 0: the library's factor_dense_blk; VAR 1: the same with per-phase stamps of wave 0 (shader clock); VAR 2 (-DWITH_R05): round 5's routine
 template <int NT, int VAR>
-__global__ void __launch_bounds__(NT) k_fac(const double *__restrict__ A, double *__restrict__ out, int R, int C, int ns, long long *stamps, int *bad) {
+__global__ void __launch_bounds__(NT) k_fac(const double *__restrict__ A, double *__restrict__ out, int R, int C, int ns, long long *stamps, int *bad, int inner) {
     extern __shared__ __attribute__((aligned(16))) double S[];
     const int ld = R | 1, Rv = R - 2;
-    for (int e = threadIdx.x; e < R * C; e += NT) { const int c = e / R, r = e - c * R; S[(size_t)c * ld + r] = A[e]; }
     double *stage = S + (size_t)ld * C;
+    long long t0 = 0;
+    for (int rep = 0; rep < inner; rep++) {          // inner > 1: the last repetition runs with the instruction cache warm
     __syncthreads();
-    const long long t0 = clock64();
+    for (int e = threadIdx.x; e < R * C; e += NT) { const int c = e / R, r = e - c * R; S[(size_t)c * ld + r] = A[e]; }
+    __syncthreads();
+    t0 = clock64();
     if constexpr (VAR == 0) factor_dense_blk<NT>(S, ld, ns, Rv, C, bad, stage, nullptr);
     else if constexpr (VAR == 2) {
 #ifdef WITH_R05
@@ -106,6 +109,7 @@ __global__ void __launch_bounds__(NT) k_fac(const double *__restrict__ A, double
             }
         }
     }
+    }
     __syncthreads();
     const long long t1 = clock64();
     if (threadIdx.x == 0) stamps[NSTAMP - 1] = t1 - t0;
@@ -121,7 +125,7 @@ static void host_factor(std::vector<double> &F, int R, int C, int ns) {      // 
     }
 }
 
-template <int NT, int VAR> static double run(const std::vector<double> &A, std::vector<double> &res, int R, int C, int ns, std::vector<long long> &st, int reps) {
+template <int NT, int VAR> static double run(const std::vector<double> &A, std::vector<double> &res, int R, int C, int ns, std::vector<long long> &st, int reps, int inner = 1) {
     double *dA, *dO; long long *dS; int *dB;
     hipMalloc(&dA, A.size() * 8); hipMalloc(&dO, A.size() * 8); hipMalloc(&dS, NSTAMP * 8); hipMalloc(&dB, 16);
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice); hipMemset(dS, 0, NSTAMP * 8); hipMemset(dB, 0, 16);
@@ -130,7 +134,7 @@ template <int NT, int VAR> static double run(const std::vector<double> &A, std::
     long long best = 1ll << 60;
     st.assign(NSTAMP, 0);
     for (int r = 0; r < reps; r++) {
-        hipLaunchKernelGGL((k_fac<NT, VAR>), dim3(1), dim3(NT), lds, 0, dA, dO, R, C, ns, dS, dB);
+        hipLaunchKernelGGL((k_fac<NT, VAR>), dim3(1), dim3(NT), lds, 0, dA, dO, R, C, ns, dS, dB, inner);
         hipDeviceSynchronize();
         std::vector<long long> s(NSTAMP); hipMemcpy(s.data(), dS, NSTAMP * 8, hipMemcpyDeviceToHost);
         if (s[NSTAMP - 1] < best) { best = s[NSTAMP - 1]; st = s; }
@@ -156,6 +160,7 @@ int main(int argc, char **argv) {
         std::vector<double> ref = A; host_factor(ref, R, C, ns);
         std::vector<double> r0, r1, r2; std::vector<long long> s0, s1, s2;
         const double c0 = run<1024, 0>(A, r0, R, C, ns, s0, 5), c1 = run<1024, 1>(A, r1, R, C, ns, s1, 5);
+        { std::vector<double> rw; std::vector<long long> sw; const double cw = run<1024, 0>(A, rw, R, C, ns, sw, 3, 4); printf("nsb %2d nub %2d: library, 4th repetition inside one launch (warm instruction cache): %6.0f cycles\n", nsb, nub, cw); }
 #ifdef WITH_R05
         const double c2 = run<1024, 2>(A, r2, R, C, ns, s2, 5);
 #else
