@@ -60,7 +60,8 @@ struct FrontDesc {
     int rows_begin;                // first entry of this front's struct rows in f_rows
     int parent;
     int dinv0;                     // first slot (NB x NB doubles each) of this front's persistent inverse diagonal blocks, -1: none (see k_block_chain)
-    int pad[4];
+    int prim1;                     // 1 + index (in this front's child range) of the child with the largest update block, 0: none (see k_assemble_big)
+    int pad[3];
 };
 static_assert(sizeof(FrontDesc) == 64, "FrontDesc must stay one cache line");
 // contributions of a destination: slots [src_begin, src_end) of Hc, or — for fronts regenerated by the
@@ -577,7 +578,8 @@ template <int NT, int MODE, bool ZERO = true>
 __device__ __forceinline__ void assemble_front(const DevPlan &P, const FrontDesc &D, const double *__restrict__ pool,
                                                const double *__restrict__ Hc, int bc0, int bc1, bool full,
                                                double *__restrict__ dstL, int ldL, double *__restrict__ dstG, int ldG, int2 *__restrict__ wl,
-                                               long long *pf = nullptr, const int *wait_flags = nullptr, int *bad = nullptr, int ev = 0) {
+                                               long long *pf = nullptr, const int *wait_flags = nullptr, int *bad = nullptr, int ev = 0, int skip_child = -1) {
+    // skip_child: a child (index in the front's child range) whose update block the caller has already STORED into the destination (k_assemble_big)
     const int tid = threadIdx.x;
     const int nsb = D.nsb, nbc = D.nsb + D.nub;     // own / all block columns
     const int R = 3 * (nbc + 1);                    // rows incl. rhs block row
@@ -758,6 +760,7 @@ __device__ __forceinline__ void assemble_front(const DevPlan &P, const FrontDesc
     auto slice_rel = [&](int q, int c0, int *cnu_out) -> int {
         if (q >= min(nch, g0 + CAPQ)) { *cnu_out = 0; return -1; }
         const ChildRec c = rec_of(q);
+        if (q == skip_child) { *cnu_out = 0; return -1; }      // (a child without blocks: the fill loop moves on)
         *cnu_out = c.cnu;
         const int jb = c0 + lane;
         return (lane < 32 && jb < c.cnu) ? P.f_rel[c.rel_begin + jb] : -1;
@@ -1537,6 +1540,13 @@ __global__ void __launch_bounds__(NT) k_front_small(DevPlan P, const int *__rest
 // big fronts
 // ------------------------------------------------------------------------------------------------------
 // work item: one chunk of ASM_CB block columns of one big front; list/pre = launch table of the level
+// Round 6: the PRIMARY child.  Until now a chunk was zero-filled, then every child's update block was added to it with L2 atomics -- and on
+// the lattices a level's chunks are far more than the L2 holds, so the zeros went to HBM, came back for the adds and went out again:
+// 2.6-2.7 x the algorithmic bytes (profiles/r05_pmc_hbm_lattice*.json).  The child with the largest update block (FrontDesc::prim1, chosen
+// at plan time) is now STORED: one pass over the chunk writes, per element, the Tikhonov term or zero PLUS that child's entry where it has
+// one (an inverse of its block map in LDS: destination block -> child block), coalesced down the rows; the other children are added on
+// top as before.  One write instead of write + read + write for every element the primary child covers, and half the atomics.
+constexpr int ASM_INV_CAP = 4096;                  // destination block rows whose inverse map fits the LDS (fronts with more: the zero-fill path)
 __global__ void __launch_bounds__(TPB) k_assemble_big(DevPlan P, const int *__restrict__ list, const int *__restrict__ pre, int n,
                                                       double *__restrict__ pool, const double *__restrict__ Hc) {
     const int a = find_seg(pre, n, blockIdx.x);
@@ -1545,7 +1555,51 @@ __global__ void __launch_bounds__(TPB) k_assemble_big(DevPlan P, const int *__re
     const int nbc = D.nsb + D.nub;
     const int bc1 = min(bc0 + ASM_CB, nbc);
     __shared__ int2 wl[wl_bytes(TPB / 64) / 8];
-    assemble_front<TPB, ASM_GLOBAL>(P, D, pool, Hc, bc0, bc1, false, nullptr, 0, pool + D.off, 3 * (nbc + 1), wl);
+    __shared__ short inv[ASM_INV_CAP];
+    const int prim = D.prim1 - 1;
+    if (prim < 0 || nbc + 1 > ASM_INV_CAP) {
+        assemble_front<TPB, ASM_GLOBAL>(P, D, pool, Hc, bc0, bc1, false, nullptr, 0, pool + D.off, 3 * (nbc + 1), wl);
+        return;
+    }
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const ChildRec cr = P.child[D.ch_begin + prim];
+    const int cnu = cr.cnu, cR = cr.cR, R = 3 * (nbc + 1);
+    for (int e = tid; e <= nbc; e += TPB) inv[e] = -1;
+    __syncthreads();
+    for (int j = tid; j < cnu; j += TPB) inv[P.f_rel[cr.rel_begin + j]] = (short)j;      // (the block map is strictly increasing: no two j meet)
+    if (tid == 0) inv[nbc] = (short)cnu;                                                   // the right-hand-side row: row 3 cnu of the child's update block
+    __syncthreads();
+    double *__restrict__ dst = pool + D.off;
+    const double *__restrict__ src = pool + cr.uoff;
+    for (int col = 3 * bc0 + wv; col < 3 * bc1; col += TPB / 64) {
+        const int bcol = col / 3, c3 = col - 3 * bcol;
+        const double lam = col < 3 * D.nsb ? P.lambda[D.first + bcol] : 0.0;
+        const int jc = __builtin_amdgcn_readfirstlane((int)inv[bcol]);
+        if (jc < 0) {                                  // (wave-uniform) a column the primary child has nothing for
+            for (int row = 3 * bcol + lane; row < R; row += 64) dst[(size_t)col * R + row] = row == col ? lam : 0.0;
+            continue;
+        }
+        const int ccol = 3 * jc + c3;
+        const double *__restrict__ scol = src + (size_t)ccol * cR;
+        for (int r0 = 3 * bcol; r0 < R; r0 += 256) {          // four loads per lane in flight
+            double v[4]; bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int row = r0 + 64 * u + lane, rc = min(row, R - 1), brow = rc / 3, i3 = rc - 3 * brow;
+                const int jr = inv[brow], crow = 3 * jr + i3;
+                // the child's entry: scalar lower triangle of its update block; its right-hand-side row (block row cnu) has one row
+                ok[u] = row < R && jr >= 0 && (brow < nbc ? crow >= ccol : i3 == 0);
+                v[u] = ld_agent(scol + (ok[u] ? crow : ccol));      // (clamped: the column's diagonal entry)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int row = r0 + 64 * u + lane;
+                if (row < R) dst[(size_t)col * R + row] = (row == col ? lam : 0.0) + (ok[u] ? v[u] : 0.0);
+            }
+        }
+    }
+    __syncthreads();
+    assemble_front<TPB, ASM_GLOBAL, false>(P, D, pool, Hc, bc0, bc1, false, nullptr, 0, dst, R, wl, nullptr, nullptr, nullptr, 0, prim);
 }
 
 // NB x NB diagonal block of a panel step, lanes = rows (lanes 32..63 mirror 0..31), columns in registers: the pinned

@@ -262,7 +262,7 @@ static void inc_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         for (int f = c.inc_F; f < F; f++) {
             const int a = gp.h_fa.p[f], b = gp.h_fb.p[f];
             c.wt[f] = (f < (int)gp.asym.size() && gp.asym[f] && b >= 0 && c.model.pos[b] < c.model.pos[a]) ? 1 : 0;
-            c.wt_any = c.wt_any || c.wt[f];
+            if (c.wt[f]) set_wt_any(c, true);
         }
     }
     std::vector<RefModel::Visit> &visits = c.visits;

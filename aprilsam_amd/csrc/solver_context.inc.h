@@ -455,6 +455,11 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
         d.ch_begin = P.ch_ptr[t]; d.ch_end = P.ch_ptr[t + 1];
         d.rows_begin = 0; d.parent = P.f_parent[t];      // rows_begin patched below (absolute offset in the int arena)
     }
+    for (int t = 0; t < P.nF; t++) {          // the child with the largest update block (k_assemble_big stores it instead of adding it to zeros)
+        int best = -1;
+        for (int k = P.ch_ptr[t]; k < P.ch_ptr[t + 1]; k++) if (P.f_nub[P.ch_idx[k]] > 0 && (best < 0 || P.f_nub[P.ch_idx[k]] > P.f_nub[P.ch_idx[best]])) best = k;
+        fd[t].prim1 = best < 0 ? 0 : best - P.ch_ptr[t] + 1;
+    }
     for (size_t k = 0; k < P.ch_idx.size(); k++) {
         const int cfr = P.ch_idx[k];
         ChildRec &r = ch[k];
@@ -769,12 +774,14 @@ static void enqueue_numeric(Context &c, GraphPack &gp, hipStream_t s, hipEvent_t
     if (io_host) hipLaunchKernelGGL(k_load_states, dim3((3 * N + TPB - 1) / TPB), dim3(TPB), 0, s, 3 * N, gp.h_state.p, gp.d_state.p, gp.d_lp.p);
     enqueue_poison(c, s, nullptr, P.nF);
     tic(K_LINEARIZE);
-    if (F >= g_opt.linearize_staged_min)
-        hipLaunchKernelGGL((k_linearize_t<true>), dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, unary_at_lp ? gp.d_upt.p : (const double *)nullptr, c.d_epoch.p);
-    else
-        hipLaunchKernelGGL((k_linearize_t<false>), dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
-                           gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, unary_at_lp ? gp.d_upt.p : (const double *)nullptr, c.d_epoch.p);
+    {   // (a variant of the kernel without the asymmetric-W orientation branch, for graphs that have no such factor, was measured in round 6: no
+        // difference -- 0.79 ms on the 1 M lattice either way)
+        auto launch = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((F + TPB - 1) / TPB), dim3(TPB), 0, s, 0, F, (const int *)nullptr, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p,
+                               gp.d_lp.p, gp.d_state.p, c.d_swap.p, c.dp.slot_blk, c.dp.slot_rhs, c.d_H.p, c.d_bad.p, unary_at_lp ? gp.d_upt.p : (const double *)nullptr, c.d_epoch.p);
+        };
+        if (F >= g_opt.linearize_staged_min) launch(k_linearize_t<true>); else launch(k_linearize_t<false>);
+    }
     if (!gp.host_idx.empty()) {         // host-evaluated factors: their blocks replace the null contributions written above
         const int nh = (int)gp.host_idx.size();
         HIPCHECK(hipMemcpyAsync(gp.d_hostH.p, gp.h_hostH.p, (size_t)33 * 8 * nh, hipMemcpyHostToDevice, s));
@@ -888,9 +895,10 @@ static long long launch_table_key() { return g_opt_epoch; }
 // (refmodel.cpp restates it, aprilsam.c:999-1249) when the graph holds factors with an asymmetric W.  Graphs without such factors -- every
 // graph the reference ships or generates -- pay one integer comparison.  Returns true when it ran the model (c.model then describes this
 // batch step: the caller need not compute it again).
+static void set_wt_any(Context &c, bool v) { c.wt_any = v; }
 static bool orient_asymmetric(Context &c, GraphPack &gp) {
     if (gp.n_asym == 0) {
-        if (c.wt_any) { c.wt.clear(); c.wt_any = false; c.wt_dirty = true; c.wt_serial = -1; }
+        if (c.wt_any) { c.wt.clear(); set_wt_any(c, false); c.wt_dirty = true; c.wt_serial = -1; }
         return false;
     }
     if (!gp.host_idx.empty()) fail(ERR_UNSUPPORTED, "factors with an asymmetric information matrix next to factors of foreign types: the reference's result depends on its elimination "
@@ -898,11 +906,13 @@ static bool orient_asymmetric(Context &c, GraphPack &gp) {
     if (c.wt_serial == gp.serial && c.wt_topo == gp.topo_version && c.wt_content == gp.content_version && (int)c.wt.size() == gp.F) return false;
     const int N = gp.N, F = gp.F;
     c.model.batch(N, F, gp.h_fa.p, gp.h_fb.p);
-    c.wt.assign((size_t)F, 0); c.wt_any = false;
+    c.wt.assign((size_t)F, 0);
+    bool any = false;
     for (int f = 0; f < F; f++) {
         const int a = gp.h_fa.p[f], b = gp.h_fb.p[f];
-        if (gp.asym[f] && b >= 0 && c.model.pos[b] < c.model.pos[a]) { c.wt[f] = 1; c.wt_any = true; }
+        if (gp.asym[f] && b >= 0 && c.model.pos[b] < c.model.pos[a]) { c.wt[f] = 1; any = true; }
     }
+    set_wt_any(c, any);
     c.wt_serial = gp.serial; c.wt_topo = gp.topo_version; c.wt_content = gp.content_version; c.wt_dirty = true;
     return true;
 }

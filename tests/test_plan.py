@@ -100,6 +100,28 @@ def test_lattice_plan_quality(lib):
     assert P.nLevels <= 16
 
 
+@pytest.mark.parametrize("case", ["m3500", "random_mid", "lattice40"])
+def test_separator_amalgamation_keeps_the_plan_valid(lib, oracle, case):
+    """option amalg (symbolic.cpp amalgamate: separator fronts take in child separators where a model of the critical path says so --
+    measured on the box and left off, profiles/r06_experiments_not_kept.txt): fewer fronts and levels, still a valid plan, and the numeric
+    emulation still solves the system"""
+    arr = {"m3500": datasets.m3500_batch, "random_mid": lambda: datasets.random_pose_graph(600, 500, 6), "lattice40": lambda: lib.lattice_arrays(40)}[case]()
+    st, fa, fb, z, W = arr
+    N = len(st)
+    P0 = PlanView(lib, N, fa, fb, xy=st[:, :2], leaf_nodes=16)
+    with lib.options(amalg=1, amalg_max=48):
+        P = PlanView(lib, N, fa, fb, xy=st[:, :2], leaf_nodes=16)
+    _check_structure(P, N, fa, fb)
+    assert P.nF <= P0.nF and P.nLevels <= P0.nLevels
+    if case == "m3500":
+        assert P.nLevels < P0.nLevels and int(P.front_nsb.max()) <= 48
+    H, G = contributions(oracle, st, st, fa, fb, z, W, P.factor_swap)
+    lam = np.full(N, 1e-4)
+    dx = solve(P, H, G, lam).reshape(N, 3)[P.pos]
+    ref = oracle.solve_system(st, st, fa, fb, z, W, lam)
+    assert np.max(np.abs(dx - ref)) < 1e-7 * max(1.0, np.max(np.abs(ref)))
+
+
 @pytest.mark.parametrize("pin", [1, 8, 40])
 def test_pin_last_keeps_the_newest_poses_in_the_root_front(lib, oracle, pin):
     """option pin_last ("recent poses last", cf. aprilsam.c:1021-1098): the k newest poses form the root front; the plan
