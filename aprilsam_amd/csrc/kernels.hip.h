@@ -296,6 +296,12 @@ __global__ void __launch_bounds__(TPB) k_scatter_host(int nh, const int *__restr
 // (b,b) block + rhs b) and writes them out with consecutive lanes on consecutive doubles of a slot: a store instruction
 // covers ~5 factors x (72 + 24 contiguous bytes) instead of 64 x 8 scattered bytes.  Wave-private, no barrier.  The direct
 // form stays for small graphs, where the kernel is one latency chain and the LDS round trips only add to it.
+// waves per SIMD k_linearize is compiled for.  The staged form needs 134 VGPRs when left alone (the f64 sincos) -- three waves per SIMD; pinned
+// to four (128 VGPRs, no spill) it is 0.67 instead of 0.79 ms on the 1 M lattice: the regression of round 5, which pushed it over 128.  Five
+// (102 VGPRs): spills, 0.85 ms.
+#ifndef LIN_WAVES
+#define LIN_WAVES 4
+#endif
 constexpr int LIN_STRIDE = 13;     // doubles per lane in the staging buffer (12 used; odd: conflict-free)
 // linearise_factor: the body, one thread per factor.  gtid = the thread's index in the launch (factor f_begin + gtid); stg / sid:
 // the staging buffers of the STAGED form (unused otherwise).
@@ -426,7 +432,7 @@ __device__ __forceinline__ void linearise_factor(int gtid, int f_begin, int f_en
 }
 
 template <bool STAGED>
-__global__ void __launch_bounds__(TPB) k_linearize_t(int f_begin, int f_end, const int *__restrict__ flist, const int *__restrict__ fa, const int *__restrict__ fb,
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(LIN_WAVES, LIN_WAVES))) k_linearize_t(int f_begin, int f_end, const int *__restrict__ flist, const int *__restrict__ fa, const int *__restrict__ fb,
                                                    const double *__restrict__ Z, const double *__restrict__ Wm,
                                                    const double *__restrict__ lp, const double *__restrict__ st,
                                                    const unsigned char *__restrict__ swp, const int *__restrict__ slot_blk,
