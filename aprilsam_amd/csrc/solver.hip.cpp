@@ -55,12 +55,12 @@ Options g_opt;
 // ONE table of the options: name (aprilsam_amd_set_option / aprilsam_amd_get_option; the environment variable is APRILSAM_AMD_<NAME>), member,
 // smallest accepted value, and whether the option is a host-side POLICY that no launch table or captured graph depends on (changing any
 // other option bumps g_opt_epoch: every param re-plans and re-captures on its next call).
-struct OptionDef { const char *name; int Options::*member; int min_value; bool policy; };
+struct OptionDef { const char *name; int Options::*member; int min_value; bool policy; int max_value = 0x7fffffff; };
 static const OptionDef OPTION_TABLE[] = {
     { "leaf_nodes", &Options::leaf_nodes, 1, false }, { "deterministic", &Options::deterministic, 0, true }, { "use_graph", &Options::use_graph, 0, true },
     { "device_timing", &Options::device_timing, 0, true }, { "trust_factor_cache", &Options::trust_factor_cache, 0, true },
     { "small_lds_kb", &Options::small_lds_kb, 0, false }, { "syrk_xcd_order", &Options::syrk_xcd_order, 0, false },
-    { "schur_first", &Options::schur_first, 0, false }, { "syrk_small_tiles", &Options::syrk_small_tiles, 0, false }, { "syrk_pair_tiles", &Options::syrk_pair_tiles, 0, false }, { "syrk_group", &Options::syrk_group, 2, false }, { "panel_mode", &Options::panel_mode, 0, false },
+    { "schur_first", &Options::schur_first, 0, false }, { "syrk_small_tiles", &Options::syrk_small_tiles, 0, false }, { "syrk_pair_tiles", &Options::syrk_pair_tiles, 0, false }, { "syrk_group", &Options::syrk_group, 2, false, 8 }, { "panel_mode", &Options::panel_mode, 0, false },
     { "small_threads", &Options::small_threads, 64, false }, { "tp_fronts", &Options::tp_fronts, 0, false }, { "tp_lds_kb", &Options::tp_lds_kb, 0, false },
     { "tp_threads", &Options::tp_threads, 64, false }, { "inc_fast", &Options::inc_fast, 0, true }, { "inc_multi", &Options::inc_multi, 0, true },
     { "inc_one", &Options::inc_one, 0, true }, { "inc_one_up", &Options::inc_one_up, 1, true }, { "inc_one_dn", &Options::inc_one_dn, 1, true },
@@ -84,7 +84,7 @@ static void load_env_options() {
             std::string env = "APRILSAM_AMD_";
             for (const char *q = d.name; *q; q++) env += (char)toupper((unsigned char)*q);
             const char *sv = getenv(env.c_str());
-            if (sv && *sv) g_opt.*(d.member) = std::max(d.min_value, (int)atof(sv));
+            if (sv && *sv) g_opt.*(d.member) = std::min(d.max_value, std::max(d.min_value, (int)atof(sv)));
         }
     });
 }
@@ -100,7 +100,7 @@ static void load_env_options() {
 // (symbolic.cpp: one plan at a time), the last-error record (errors.cpp).  The options (aprilsam_amd_set_option) are process-global
 // and are meant to be set while no call is in flight.
 constexpr int MAX_SLOTS = 64;
-static int g_device = -1;                         // the process default slot
+static std::atomic<int> g_device{ -1 };          // the process default slot (read by every call that is not bound to a slot, written by aprilsam_amd_set_device / the first call)
 static std::mutex g_slot_mu[MAX_SLOTS];
 static thread_local int t_slot = 0;               // slot of the call in progress on this thread
 static int device_count() {
@@ -125,7 +125,7 @@ template <class V> struct Registry {             // std::map: iterators and elem
 };
 static std::map<const void *, int> g_param_slot; static std::mutex g_param_slot_mu;      // aprilsam_amd_param_set_device
 static std::atomic<int> g_param_slot_n{ 0 };      // bound params (zero: every call takes the default slot without looking)
-static int default_slot() { return g_device < 0 ? 0 : g_device % MAX_SLOTS; }
+static int default_slot() { const int d = g_device.load(std::memory_order_relaxed); return d < 0 ? 0 : d % MAX_SLOTS; }
 static int slot_of_graph(const void *g);          // solver_pack.inc.h: the slot its pack lives on, or -1
 static int slot_for(const void *param, const void *g) {
     if (param && g_param_slot_n.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(g_param_slot_mu); auto it = g_param_slot.find(param); if (it != g_param_slot.end()) return it->second; }
@@ -340,6 +340,7 @@ int api_set_device(int d) {
 // bind a param (and, through it, the pack of the graph it is called with) to a device slot; whatever the param held is dropped
 int api_param_set_device(const april_graph_cholesky_param_t *param, int slot) {
     if (!param || slot < 0 || slot >= MAX_SLOTS) return -1;
+    { SlotLock lk0(param, nullptr); drop_shard_state(param); }      // (a sharded solve's buffers and communicator live on the old slot's device too)
     drop_context(param);                            // (under the lock of the slot it was on)
     std::lock_guard<std::mutex> lk(g_param_slot_mu);
     g_param_slot[param] = slot;
@@ -358,7 +359,7 @@ int api_set_option(const char *name, double v) {
     load_env_options();
     const OptionDef *d = name ? find_option(name) : nullptr;
     if (!d) return -1;
-    const int nv = std::max(d->min_value, (int)v);
+    const int nv = std::min(d->max_value, std::max(d->min_value, (int)v));
     if (g_opt.*(d->member) == nv) return 0;
     g_opt.*(d->member) = nv;
     if (!d->policy) g_opt_epoch++;

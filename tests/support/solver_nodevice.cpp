@@ -61,11 +61,15 @@ void unbind_param(const april_graph_cholesky_param_t *) {}
 int api_set_option(const char *name, double v) {
     if (name && !strcmp(name, "leaf_nodes")) { g_opt.leaf_nodes = (int)v; return 0; }
     if (name && !strcmp(name, "pin_last")) { g_opt.pin_last = (int)v; return 0; }
+    if (name && !strcmp(name, "amalg")) { g_opt.amalg = (int)v; return 0; }
+    if (name && !strcmp(name, "amalg_max")) { g_opt.amalg_max = (int)v; return 0; }
     return -1;
 }
 int api_get_option(const char *name, double *v) {
     if (name && v && !strcmp(name, "leaf_nodes")) { *v = g_opt.leaf_nodes; return 0; }
     if (name && v && !strcmp(name, "pin_last")) { *v = g_opt.pin_last; return 0; }
+    if (name && v && !strcmp(name, "amalg")) { *v = g_opt.amalg; return 0; }
+    if (name && v && !strcmp(name, "amalg_max")) { *v = g_opt.amalg_max; return 0; }
     return -1;
 }
 
