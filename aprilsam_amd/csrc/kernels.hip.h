@@ -60,8 +60,8 @@ struct FrontDesc {
     int rows_begin;                // first entry of this front's struct rows in f_rows
     int parent;
     int dinv0;                     // first slot (NB x NB doubles each) of this front's persistent inverse diagonal blocks, -1: none (see k_block_chain)
-    int prim1;                     // 1 + index (in this front's child range) of the child with the largest update block, 0: none (see k_assemble_big)
-    int pad[3];
+    int prim1, prim2;              // 1 + index (in this front's child range) of the children with the largest / second largest update block, 0: none (see k_assemble_big)
+    int pad[2];
 };
 static_assert(sizeof(FrontDesc) == 64, "FrontDesc must stay one cache line");
 // contributions of a destination: slots [src_begin, src_end) of Hc, or — for fronts regenerated by the
@@ -584,8 +584,8 @@ template <int NT, int MODE, bool ZERO = true>
 __device__ __forceinline__ void assemble_front(const DevPlan &P, const FrontDesc &D, const double *__restrict__ pool,
                                                const double *__restrict__ Hc, int bc0, int bc1, bool full,
                                                double *__restrict__ dstL, int ldL, double *__restrict__ dstG, int ldG, int2 *__restrict__ wl,
-                                               long long *pf = nullptr, const int *wait_flags = nullptr, int *bad = nullptr, int ev = 0, int skip_child = -1) {
-    // skip_child: a child (index in the front's child range) whose update block the caller has already STORED into the destination (k_assemble_big)
+                                               long long *pf = nullptr, const int *wait_flags = nullptr, int *bad = nullptr, int ev = 0, int skip_child = -1, int skip_child2 = -1) {
+    // skip_child(2): children (index in the front's child range) whose update blocks the caller has already STORED into the destination (k_assemble_big)
     const int tid = threadIdx.x;
     const int nsb = D.nsb, nbc = D.nsb + D.nub;     // own / all block columns
     const int R = 3 * (nbc + 1);                    // rows incl. rhs block row
@@ -766,7 +766,7 @@ __device__ __forceinline__ void assemble_front(const DevPlan &P, const FrontDesc
     auto slice_rel = [&](int q, int c0, int *cnu_out) -> int {
         if (q >= min(nch, g0 + CAPQ)) { *cnu_out = 0; return -1; }
         const ChildRec c = rec_of(q);
-        if (q == skip_child) { *cnu_out = 0; return -1; }      // (a child without blocks: the fill loop moves on)
+        if (q == skip_child || q == skip_child2) { *cnu_out = 0; return -1; }      // (a child without blocks: the fill loop moves on)
         *cnu_out = c.cnu;
         const int jb = c0 + lane;
         return (lane < 32 && jb < c.cnu) ? P.f_rel[c.rel_begin + jb] : -1;
@@ -1546,13 +1546,14 @@ __global__ void __launch_bounds__(NT) k_front_small(DevPlan P, const int *__rest
 // big fronts
 // ------------------------------------------------------------------------------------------------------
 // work item: one chunk of ASM_CB block columns of one big front; list/pre = launch table of the level
-// Round 6: the PRIMARY child.  Until now a chunk was zero-filled, then every child's update block was added to it with L2 atomics -- and on
+// Round 6: STORED children.  Until now a chunk was zero-filled, then every child's update block was added to it with L2 atomics -- and on
 // the lattices a level's chunks are far more than the L2 holds, so the zeros went to HBM, came back for the adds and went out again:
-// 2.6-2.7 x the algorithmic bytes (profiles/r05_pmc_hbm_lattice*.json).  The child with the largest update block (FrontDesc::prim1, chosen
-// at plan time) is now STORED: one pass over the chunk writes, per element, the Tikhonov term or zero PLUS that child's entry where it has
-// one (an inverse of its block map in LDS: destination block -> child block), coalesced down the rows; the other children are added on
-// top as before.  One write instead of write + read + write for every element the primary child covers, and half the atomics.
-constexpr int ASM_INV_CAP = 4096;                  // destination block rows whose inverse map fits the LDS (fronts with more: the zero-fill path)
+// 2.6-2.7 x the algorithmic bytes (profiles/r05_pmc_hbm_lattice*.json).  The two children with the largest update blocks (FrontDesc::prim1 /
+// prim2, chosen at plan time; a dissection front has two children) are now STORED: one pass over the chunk writes, per element, the Tikhonov
+// term or zero PLUS those children's entries where they have one (an inverse of each block map in LDS: destination block -> child block),
+// coalesced down the rows, always in the order term + first + second; any further children and the factor blocks are added on top as before.
+// One write per element instead of write + read + write per contributing child, and no atomics at all for a front with two children.
+constexpr int ASM_INV_CAP = 4096;                  // destination block rows whose inverse maps fit the LDS (fronts with more: the zero-fill path)
 __global__ void __launch_bounds__(TPB) k_assemble_big(DevPlan P, const int *__restrict__ list, const int *__restrict__ pre, int n,
                                                       double *__restrict__ pool, const double *__restrict__ Hc) {
     const int a = find_seg(pre, n, blockIdx.x);
@@ -1561,51 +1562,54 @@ __global__ void __launch_bounds__(TPB) k_assemble_big(DevPlan P, const int *__re
     const int nbc = D.nsb + D.nub;
     const int bc1 = min(bc0 + ASM_CB, nbc);
     __shared__ int2 wl[wl_bytes(TPB / 64) / 8];
-    __shared__ short inv[ASM_INV_CAP];
-    const int prim = D.prim1 - 1;
+    __shared__ short inv[2][ASM_INV_CAP];
+    const int prim = D.prim1 - 1, sec = D.prim2 - 1;
     if (prim < 0 || nbc + 1 > ASM_INV_CAP) {
         assemble_front<TPB, ASM_GLOBAL>(P, D, pool, Hc, bc0, bc1, false, nullptr, 0, pool + D.off, 3 * (nbc + 1), wl);
         return;
     }
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const ChildRec cr = P.child[D.ch_begin + prim];
-    const int cnu = cr.cnu, cR = cr.cR, R = 3 * (nbc + 1);
-    for (int e = tid; e <= nbc; e += TPB) inv[e] = -1;
+    const int nst = sec >= 0 ? 2 : 1;                          // stored children
+    const ChildRec cr0 = P.child[D.ch_begin + prim], cr1 = P.child[D.ch_begin + max(sec, 0)];
+    const int R = 3 * (nbc + 1);
+    for (int e = tid; e <= nbc; e += TPB) { inv[0][e] = -1; inv[1][e] = -1; }
     __syncthreads();
-    for (int j = tid; j < cnu; j += TPB) inv[P.f_rel[cr.rel_begin + j]] = (short)j;      // (the block map is strictly increasing: no two j meet)
-    if (tid == 0) inv[nbc] = (short)cnu;                                                   // the right-hand-side row: row 3 cnu of the child's update block
+    for (int j = tid; j < cr0.cnu; j += TPB) inv[0][P.f_rel[cr0.rel_begin + j]] = (short)j;      // (a block map is strictly increasing: no two j meet)
+    if (nst > 1) for (int j = tid; j < cr1.cnu; j += TPB) inv[1][P.f_rel[cr1.rel_begin + j]] = (short)j;
+    if (tid == 0) { inv[0][nbc] = (short)cr0.cnu; if (nst > 1) inv[1][nbc] = (short)cr1.cnu; }     // the right-hand-side row: row 3 cnu of a child's update block
     __syncthreads();
     double *__restrict__ dst = pool + D.off;
-    const double *__restrict__ src = pool + cr.uoff;
     for (int col = 3 * bc0 + wv; col < 3 * bc1; col += TPB / 64) {
         const int bcol = col / 3, c3 = col - 3 * bcol;
         const double lam = col < 3 * D.nsb ? P.lambda[D.first + bcol] : 0.0;
-        const int jc = __builtin_amdgcn_readfirstlane((int)inv[bcol]);
-        if (jc < 0) {                                  // (wave-uniform) a column the primary child has nothing for
+        const int jc0 = __builtin_amdgcn_readfirstlane((int)inv[0][bcol]), jc1 = nst > 1 ? __builtin_amdgcn_readfirstlane((int)inv[1][bcol]) : -1;
+        if (jc0 < 0 && jc1 < 0) {                              // (wave-uniform) a column neither stored child has anything for
             for (int row = 3 * bcol + lane; row < R; row += 64) dst[(size_t)col * R + row] = row == col ? lam : 0.0;
             continue;
         }
-        const int ccol = 3 * jc + c3;
-        const double *__restrict__ scol = src + (size_t)ccol * cR;
-        for (int r0 = 3 * bcol; r0 < R; r0 += 256) {          // four loads per lane in flight
-            double v[4]; bool ok[4];
+        const int cc0 = 3 * max(jc0, 0) + c3, cc1 = 3 * max(jc1, 0) + c3;
+        const double *__restrict__ s0 = pool + cr0.uoff + (size_t)cc0 * cr0.cR, *__restrict__ s1 = pool + cr1.uoff + (size_t)cc1 * cr1.cR;
+        for (int r0 = 3 * bcol; r0 < R; r0 += 128) {          // four loads per lane in flight
+            double v0[2], v1[2]; bool ok0[2], ok1[2];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 2; u++) {
                 const int row = r0 + 64 * u + lane, rc = min(row, R - 1), brow = rc / 3, i3 = rc - 3 * brow;
-                const int jr = inv[brow], crow = 3 * jr + i3;
-                // the child's entry: scalar lower triangle of its update block; its right-hand-side row (block row cnu) has one row
-                ok[u] = row < R && jr >= 0 && (brow < nbc ? crow >= ccol : i3 == 0);
-                v[u] = ld_agent(scol + (ok[u] ? crow : ccol));      // (clamped: the column's diagonal entry)
+                // a child's entry: scalar lower triangle of its update block; its right-hand-side row (block row cnu) has one row
+                const int jr0 = inv[0][brow], cr_0 = 3 * jr0 + i3, jr1 = inv[1][brow], cr_1 = 3 * jr1 + i3;
+                ok0[u] = row < R && jc0 >= 0 && jr0 >= 0 && (brow < nbc ? cr_0 >= cc0 : i3 == 0);
+                ok1[u] = row < R && jc1 >= 0 && jr1 >= 0 && (brow < nbc ? cr_1 >= cc1 : i3 == 0);
+                v0[u] = ld_agent(s0 + (ok0[u] ? cr_0 : cc0));      // (clamped: the column's diagonal entry)
+                v1[u] = ld_agent(s1 + (ok1[u] ? cr_1 : cc1));
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 2; u++) {
                 const int row = r0 + 64 * u + lane;
-                if (row < R) dst[(size_t)col * R + row] = (row == col ? lam : 0.0) + (ok[u] ? v[u] : 0.0);
+                if (row < R) dst[(size_t)col * R + row] = ((row == col ? lam : 0.0) + (ok0[u] ? v0[u] : 0.0)) + (ok1[u] ? v1[u] : 0.0);
             }
         }
     }
     __syncthreads();
-    assemble_front<TPB, ASM_GLOBAL, false>(P, D, pool, Hc, bc0, bc1, false, nullptr, 0, dst, R, wl, nullptr, nullptr, nullptr, 0, prim);
+    assemble_front<TPB, ASM_GLOBAL, false>(P, D, pool, Hc, bc0, bc1, false, nullptr, 0, dst, R, wl, nullptr, nullptr, nullptr, 0, prim, sec);
 }
 
 // NB x NB diagonal block of a panel step, lanes = rows (lanes 32..63 mirror 0..31), columns in registers: the pinned

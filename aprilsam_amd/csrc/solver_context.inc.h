@@ -456,9 +456,10 @@ static void upload_plan(Context &c, hipStream_t s, const ShardLayout *lay = null
         d.rows_begin = 0; d.parent = P.f_parent[t];      // rows_begin patched below (absolute offset in the int arena)
     }
     for (int t = 0; t < P.nF; t++) {          // the child with the largest update block (k_assemble_big stores it instead of adding it to zeros)
-        int best = -1;
+        int best = -1, second = -1;
         for (int k = P.ch_ptr[t]; k < P.ch_ptr[t + 1]; k++) if (P.f_nub[P.ch_idx[k]] > 0 && (best < 0 || P.f_nub[P.ch_idx[k]] > P.f_nub[P.ch_idx[best]])) best = k;
-        fd[t].prim1 = best < 0 ? 0 : best - P.ch_ptr[t] + 1;
+        for (int k = P.ch_ptr[t]; k < P.ch_ptr[t + 1]; k++) if (k != best && P.f_nub[P.ch_idx[k]] > 0 && (second < 0 || P.f_nub[P.ch_idx[k]] > P.f_nub[P.ch_idx[second]])) second = k;
+        fd[t].prim1 = best < 0 ? 0 : best - P.ch_ptr[t] + 1; fd[t].prim2 = second < 0 ? 0 : second - P.ch_ptr[t] + 1;
     }
     for (size_t k = 0; k < P.ch_idx.size(); k++) {
         const int cfr = P.ch_idx[k];

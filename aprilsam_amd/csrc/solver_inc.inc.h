@@ -476,7 +476,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
         if (tail) { kb = I.kids[t].data(); ke = kb + I.kids[t].size(); }
         else { kb = P.ch_idx.data() + P.ch_ptr[t]; ke = P.ch_idx.data() + P.ch_ptr[t + 1]; }
         D.ch_begin = (int)(child_base + (long long)st_child.size());
-        D.prim1 = 0;                                   // (a regenerated front's children are re-staged: no primary child for k_assemble_big)
+        D.prim1 = 0; D.prim2 = 0;                      // (a regenerated front's children are re-staged: no stored children for k_assemble_big)
         for (const int *kp = kb; kp != ke; kp++) {
             const int ch = *kp;
             const int cnsb = nsb_of(ch), cnub0 = nub0_of(ch);
