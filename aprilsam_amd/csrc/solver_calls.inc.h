@@ -115,8 +115,10 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         static bool warned = false;
         if (!warned) { fprintf(stderr, "aprilsam_amd: information matrix not positive definite; node states left untouched\n"); warned = true; }
     } else {
-        // write back: state / delta_X where not NaN-skipped (l_point and UID went in above)
+        // write back: state / delta_X where not NaN-skipped (l_point and UID went in above).  Three dependent loads per node (pointer array ->
+        // node object -> its state / delta_X arrays, each a heap block of its own): the objects a few nodes ahead are requested early
         for (int i = N - 1; i >= 0; i--) {                                   // aprilsam.c:311-315 order
+            if (i >= 8) { const april_graph_node_t *p = ns[i - 8]; __builtin_prefetch(p->state, 1); __builtin_prefetch(p->delta_X, 1); }
             april_graph_node_t *n = ns[i];
             const double *dx = gp.h_dx.p + (size_t)3 * i;
             if (std::isnan(dx[0]) || std::isnan(dx[1]) || std::isnan(dx[2])) continue;   // april_graph_xyt.c:304-305
@@ -130,7 +132,7 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         param->nreordering = N;
         param->factor_num = gp.Fg;      // (graph factors; F counts packed entries, pack_factors)
         c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = model_ready;
-        if (!hybrid) inc_prepare(c);                     // (an extended plan keeps its base + tail bookkeeping)
+        if (!hybrid && !(reused && c.inc.ready && c.inc.pristine)) inc_prepare(c);      // (an extended plan keeps its base + tail bookkeeping; a warm call on an untouched plan its tables: rebuilding them was 40 % of the call's time behind the stream sync)
         c.inc_F = F; c.inc_N = N;
         record_unary_points(gp, 0, F, gp.h_state.p);         // the linearisation point of this call
         if (param->delta_x) {                                                // aprilsam.c:363-366

@@ -27,6 +27,7 @@ struct LevelPlan {
 // form one growing TAIL front at the root, and only fronts on the root paths of changed leaves are regenerated
 struct IncState {
     bool ready = false;                     // helper tables below are built for the current base plan
+    bool pristine = false;                  // ... and no incremental / extended-plan step has touched them since (inc_prepare need not run again for the same plan)
     int Nb = 0, Fb = 0, nF0 = 0, nLev0 = 0;
     int cap_nodes = 0, cap_fact = 0;         // slack reserved at plan upload (0 until the param has seen an incremental call)
     long long i32_used = 0, dest_used = 0, child_used = 0, tab_used = 0, pool_used = 0, pool_cap = 0, o_rows = 0, o_rel = 0;

@@ -37,7 +37,7 @@ static void inc_prepare(Context &c) {        // after a full (re)plan: c.plan is
     for (const LevelPlan &L : c.levels) I.base_has_big = I.base_has_big || L.n_big > 0;
     I.base_levels = c.levels;
     c.inc_slot_blk.clear(); c.inc_slot_rhs.clear();
-    I.ready = true;
+    I.ready = true; I.pristine = true;
 }
 
 // Regenerate the dirty part of the plan for nodes [Nold, N) / factors [Fold, F) and run the numeric phase on it.
@@ -50,6 +50,7 @@ static bool inc_fast_step(Context &c, GraphPack &gp, int N, int F, int Fold, int
                           bool patch_states = false) {
     IncState &I = c.inc; Plan &P = c.plan;
     const bool batch = batch_lambda >= 0;
+    I.pristine = false;
     if (!I.ready || N < I.Nb || Fold < I.Fb) return inc_fail(1);
     // an option that launch tables, front layouts (tail_poses: the padded shape of the last tail front) or captured graphs depend
     // on changed since this plan was made: the frozen base + tail structures were built under the old values -- full re-plan
