@@ -994,7 +994,10 @@ __device__ __forceinline__ void chain_block(double *S, int ld, int k0, int wdt, 
     const bool isdiag = lane < BWT;
     const int below0 = k0 + wdt;
     const int nchunk = max(1, (Rv - below0 + BROWS - 1) / BROWS);
-    for (int ch = wave; ch < nchunk; ch += nwc) {
+    // (the wave's chunks from the last to the first: chunk 0 -- whose diagonal block goes out through Dd -- is then the LAST one its wave runs, and Dd
+    // takes over the registers of D instead of living beside them through later chunks: with the copy made first, k_front_small<1024> spilled)
+    if (wave >= nchunk) return;
+    for (int ch = wave + ((nchunk - 1 - wave) / nwc) * nwc; ch >= wave; ch -= nwc) {
         const int row = isdiag ? k0 + lane : below0 + BROWS * ch + (lane - BWT);
         const bool valid = isdiag ? lane < wdt : row < Rv;
         const int rowc = valid ? row : k0;
@@ -1082,16 +1085,23 @@ __device__ __forceinline__ void factor_dense_blk(double *S, int ld, int ns, int 
     constexpr int NW = NT / 64;
     long long t_chain = 0, t_syrk = 0, t0 = 0;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double Dd[BW];                                 // the diagonal block of the chain just run, in wave 0's registers (chain_block)
-    auto chain = [&](int k0, int nwc) {
+    // one block's pivot chain on this wave's chunks of rows, the workgroup barrier behind it, and -- on wave 0, which ran chunk 0 -- the factored
+    // diagonal block from its registers into the front (a handful of LDS stores that nothing on the critical path waits for).  Dd lives inside
+    // this call only: declared outside, conditionally written and conditionally read, it stayed live through every other phase of the loop
+    // and k_front_small<1024> spilled (1.8 MB of scratch traffic per launch in the counters).
+    auto chain_sync_store = [&](int k0, int nwc) {
         const int wdt = min(BW, ns - k0);
-        if (wdt <= 8) { double (&D8)[8] = reinterpret_cast<double (&)[8]>(Dd); chain_block<NT, 8>(S, ld, k0, wdt, Rv, bad, D8, nwc); }
-        else chain_block<NT, 16>(S, ld, k0, wdt, Rv, bad, Dd, nwc);
-    };
-    auto finish = [&](int k0) {                    // (behind a barrier; one wave, a handful of LDS stores that nothing on the critical path waits for)
-        if (wave != 0) return;
-        const int wdt = min(BW, ns - k0);
-        if (wdt <= 8) chain_store_diag<8>(S, ld, k0, wdt, reinterpret_cast<const double (&)[8]>(Dd)); else chain_store_diag<16>(S, ld, k0, wdt, Dd);
+        if (wdt <= 8) {
+            double D8[8];
+            chain_block<NT, 8>(S, ld, k0, wdt, Rv, bad, D8, nwc);
+            __syncthreads();
+            if (wave == 0) chain_store_diag<8>(S, ld, k0, wdt, D8);
+        } else {
+            double D16[16];
+            chain_block<NT, 16>(S, ld, k0, wdt, Rv, bad, D16, nwc);
+            __syncthreads();
+            if (wave == 0) chain_store_diag<16>(S, ld, k0, wdt, D16);
+        }
     };
     auto chain_waves = [&](int k0) {               // waves that get a chunk of rows of block k0's chain, at most half of them
         const int wdt = min(BW, ns - k0), brows = 64 - (wdt <= 8 ? 8 : 16);
@@ -1099,9 +1109,7 @@ __device__ __forceinline__ void factor_dense_blk(double *S, int ld, int ns, int 
         return min(nchunk, NW / 2);
     };
     if (pf) t0 = wall_clock64();
-    chain(0, NW);
-    __syncthreads();
-    finish(0);
+    chain_sync_store(0, NW);
     if (pf) { const long long t1 = wall_clock64(); t_chain += t1 - t0; t0 = t1; }
     for (int k0 = 0; k0 < ns; k0 += BW) {
         const int wdt = min(BW, ns - k0), below0 = k0 + wdt;
@@ -1112,15 +1120,15 @@ __device__ __forceinline__ void factor_dense_blk(double *S, int ld, int ns, int 
             else lds_syrk16<NT>(S, ld, k0, below0, below0, next_hi, Rv);
             __syncthreads();
             if (pf) { const long long t1 = wall_clock64(); t_syrk += t1 - t0; t0 = t1; }
-            if (wave < cw) {
+            if (wave < cw) {                       // (wave-uniform: every wave meets exactly one barrier on either side)
                 long long w0_ = 0, c0_ = 0;
                 if (pf) { w0_ = wall_clock64(); c0_ = clock64(); }
-                chain(below0, cw);
+                chain_sync_store(below0, cw);
                 if (pf && threadIdx.x == 0) { pf[10] += clock64() - c0_; pf[15] += wall_clock64() - w0_; }
+            } else {
+                if (next_hi < hi) lds_syrk16<NT>(S, ld, k0, below0, next_hi, hi, Rv, cw, NW - cw);
+                __syncthreads();
             }
-            else if (next_hi < hi) lds_syrk16<NT>(S, ld, k0, below0, next_hi, hi, Rv, cw, NW - cw);
-            __syncthreads();
-            finish(below0);
             if (pf) { const long long t1 = wall_clock64(); t_chain += t1 - t0; t0 = t1; }
         } else {
             __syncthreads();
