@@ -56,9 +56,9 @@ __device__ __forceinline__ void old_lds_syrk16(double *__restrict__ S, int ld, i
 #endif
 // VAR 0: the library's factor_dense_blk; VAR 1: the same with per-phase stamps of wave 0 (shader clock); VAR 2 (-DWITH_R05): round 5's routine
 template <int NT, int VAR>
-__global__ void __launch_bounds__(NT) k_fac(const double *__restrict__ A, double *__restrict__ out, int R, int C, int ns, long long *stamps, int *bad, int inner) {
+__global__ void __launch_bounds__(NT) k_fac(const double *__restrict__ A, double *__restrict__ out, int R, int C, int ns, long long *stamps, int *bad, int inner, int ld) {
     extern __shared__ __attribute__((aligned(16))) double S[];
-    const int ld = R | 1, Rv = R - 2;
+    const int Rv = R - 2;
     double *stage = S + (size_t)ld * C;
     long long t0 = 0;
     for (int rep = 0; rep < inner; rep++) {          // inner > 1: the last repetition runs with the instruction cache warm
@@ -125,16 +125,17 @@ static void host_factor(std::vector<double> &F, int R, int C, int ns) {      // 
     }
 }
 
-template <int NT, int VAR> static double run(const std::vector<double> &A, std::vector<double> &res, int R, int C, int ns, std::vector<long long> &st, int reps, int inner = 1) {
+template <int NT, int VAR> static double run(const std::vector<double> &A, std::vector<double> &res, int R, int C, int ns, std::vector<long long> &st, int reps, int inner = 1, int ld = 0) {
+    if (!ld) ld = R | 1;
     double *dA, *dO; long long *dS; int *dB;
     hipMalloc(&dA, A.size() * 8); hipMalloc(&dO, A.size() * 8); hipMalloc(&dS, NSTAMP * 8); hipMalloc(&dB, 16);
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice); hipMemset(dS, 0, NSTAMP * 8); hipMemset(dB, 0, 16);
-    const size_t lds = (size_t)(R | 1) * C * 8 + wl_bytes(NT / 64);
+    const size_t lds = (size_t)ld * C * 8 + wl_bytes(NT / 64);
     hipFuncSetAttribute((const void *)k_fac<NT, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     long long best = 1ll << 60;
     st.assign(NSTAMP, 0);
     for (int r = 0; r < reps; r++) {
-        hipLaunchKernelGGL((k_fac<NT, VAR>), dim3(1), dim3(NT), lds, 0, dA, dO, R, C, ns, dS, dB, inner);
+        hipLaunchKernelGGL((k_fac<NT, VAR>), dim3(1), dim3(NT), lds, 0, dA, dO, R, C, ns, dS, dB, inner, ld);
         hipDeviceSynchronize();
         std::vector<long long> s(NSTAMP); hipMemcpy(s.data(), dS, NSTAMP * 8, hipMemcpyDeviceToHost);
         if (s[NSTAMP - 1] < best) { best = s[NSTAMP - 1]; st = s; }
@@ -161,6 +162,13 @@ int main(int argc, char **argv) {
         std::vector<double> r0, r1, r2; std::vector<long long> s0, s1, s2;
         const double c0 = run<1024, 0>(A, r0, R, C, ns, s0, 5), c1 = run<1024, 1>(A, r1, R, C, ns, s1, 5);
         { std::vector<double> rw; std::vector<long long> sw; const double cw = run<1024, 0>(A, rw, R, C, ns, sw, 3, 4); printf("nsb %2d nub %2d: library, 4th repetition inside one launch (warm instruction cache): %6.0f cycles\n", nsb, nub, cw); }
+        for (int m : { 15, 17, 16, 1, 9 }) {          // leading dimension of the LDS array: the smallest one >= R that is m (mod 32)
+            int ldm = R; while ((ldm & 31) != m) ldm++;
+            if ((size_t)ldm * C * 8 + wl_bytes(16) > 160 * 1024) continue;
+            std::vector<double> rw; std::vector<long long> sw; const double cw = run<1024, 0>(A, rw, R, C, ns, sw, 5, 1, ldm);
+            bool eq = true; for (int c = 0; c < C; c++) for (int r = c; r < R - 2; r++) eq = eq && rw[(size_t)c * R + r] == r0[(size_t)c * R + r];
+            printf("   leading dimension %3d (= %2d mod 32; R | 1 = %d): %6.0f cycles, bitwise equal %d\n", ldm, m, R | 1, cw, (int)eq);
+        }
 #ifdef WITH_R05
         const double c2 = run<1024, 2>(A, r2, R, C, ns, s2, 5);
 #else
