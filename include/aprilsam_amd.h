@@ -349,6 +349,9 @@ void aprilsam_amd_clear_error(void);
  *                       with NaN when the plan is uploaded and checked after every synchronised step: a kernel that wrote into one ends the
  *                       call with error -16, a kernel that READ from one and used the value turns the results into NaN -- instead of a fault
  *                       that depends on where the allocation ends.  0 = off (default)
+ *   "amalg", "amalg_max"  1: separator fronts of the nested dissection take in child separators where a model of the critical path (hand-over per
+ *                       front against pivot chain per column) says so, up to amalg_max own poses (default 64) -- fewer dependent levels, more flops.
+ *                       Measured on M3500 in round 6: no gain (profiles/r06_experiments_not_kept.txt); 0 = off (default)
  *   "pool_poison"       debug, 1: before every step the UPDATE block of every front the step (re)factorises -- what its parent reads -- and the
  *                       solution at its own positions -- what its children read -- are filled with NaN.  A dependency wait of a multi-level
  *                       launch that passes early then produces NaN / "not positive definite" with certainty instead of the previous step's
