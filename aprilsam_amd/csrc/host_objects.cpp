@@ -267,6 +267,19 @@ void aprilsam_amd_graph_from_arrays(april_graph_t *g, int N, const double *state
     free(Wm);
 }
 
+// bulk read of the node objects (state / l_point / delta_X, april_graph_xyt.c:302-314 fields): what a checker of a big graph
+// needs without a million ctypes round trips; any of the three destinations may be null
+void aprilsam_amd_graph_node_arrays(const april_graph_t *g, double *state, double *l_point, double *delta_X) {
+    const int N = g && g->nodes ? g->nodes->size : 0;
+    april_graph_node_t *const *ns = N ? (april_graph_node_t *const *)g->nodes->data : nullptr;
+    for (int i = 0; i < N; i++) {
+        const april_graph_node_t *n = ns[i];
+        if (state) memcpy(state + 3 * (size_t)i, n->state, 24);
+        if (l_point) memcpy(l_point + 3 * (size_t)i, n->l_point, 24);
+        if (delta_X) memcpy(delta_X + 3 * (size_t)i, n->delta_X, 24);
+    }
+}
+
 // ---- synthetic Manhattan lattice, SURVEY.md §8(d) config 4/5 -------------------------------------------
 // K x K poses on a unit grid, snake numbering id(r,c) = r*K + (r odd ? K-1-c : c); truth = (c, r, r odd ? pi : 0);
 // splitmix64 PRNG (state 0x9E3779B97F4A7C15, first output after state += gamma); u01 = (x >> 11) * 2^-53;

@@ -3,6 +3,12 @@
 // ------------------------------------------------------------------------------------------------------
 // one batch Gauss-Newton step through the reference API (aprilsam.c:87-375)
 // ------------------------------------------------------------------------------------------------------
+// APRILSAM_AMD_INC_PROFILE=1: host wall-clock split of the batch calls that made a new plan (the fall-backs of an incremental run), printed at exit
+static double g_fbprof[6] = { 0 }; static long long g_fbprof_n = 0;
+static const bool g_fbprof_on = [] { const char *e = getenv("APRILSAM_AMD_INC_PROFILE"); return e && (*e == '1' || *e == '2'); }();
+struct FbProfPrint { ~FbProfPrint() { if (g_fbprof_on && g_fbprof_n) fprintf(stderr, "aprilsam_amd inc profile, batch calls with a new plan: %lld, ms per call: enqueue %.3f model %.3f l_point walk %.3f retired graphs %.3f wait for the GPU %.3f\n",
+    g_fbprof_n, g_fbprof[0] / g_fbprof_n, g_fbprof[1] / g_fbprof_n, g_fbprof[2] / g_fbprof_n, g_fbprof[3] / g_fbprof_n, g_fbprof[4] / g_fbprof_n); } };
+static FbProfPrint g_fbprof_print;
 static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
     Context &c = ctx_for(param);
     GraphPack &gp = pack_for(g);
@@ -95,18 +101,26 @@ static void batch_impl(april_graph_t *g, april_graph_cholesky_param_t *param) {
         c.h_bad.p[0] = c.h_bad.p[1] = c.h_bad.p[2] = c.h_bad.p[3] = 0;          // (the kernels only ever write a SET failure record)
         run_numeric(c, gp, timing, false, true);
     }
+    const bool fbp = g_fbprof_on && !hybrid && !speculate && !reused;
+    const double f0 = fbp ? now_ms() : 0;
     // while the GPU works: a param that is used incrementally needs the reference's elimination tree of THIS batch step for
-    // its next april_graph_cholesky_inc (refmodel.cpp: the reference's own min-degree order, ~1 ms of integer work on M3500)
+    // its next april_graph_cholesky_inc (refmodel.cpp: the reference's own min-degree order, 0.3-0.5 ms of integer work at M3500's sizes).
+    // (Round 6 ran it on a thread of its own beside the planner / the extension of the plan: the calls that make a new plan gained 0.25 ms
+    // each, the others lost as much to the thread's start and its cold caches -- the demo's 50 fall-backs 26.9 against 26.6 ms: not kept.)
     bool model_ready = model_by_orientation;
     if (c.used_inc && gp.host_idx.empty() && !model_ready) { c.model.batch(N, F, gp.h_fa.p, gp.h_fb.p); model_ready = true; }      // (not for params that only ever see batch calls)
+    const double f1 = fbp ? now_ms() : 0;
     // ... and the part of the write-back that does not wait for the result: every node is re-linearised at the state it came
     // in with before anything is solved (aprilsam.c:131-135: l_point = state, whatever the factorisation says later), UID = index
     // (aprilsam.c:628).  The walk also pulls the node objects into the cache for the second half below.
     april_graph_node_t **ns = (april_graph_node_t **)g->nodes->data;
     for (int i = N - 1; i >= 0; i--) { april_graph_node_t *n = ns[i]; n->UID = i; memcpy(n->l_point, gp.h_state.p + (size_t)3 * i, 24); }
+    const double f2 = fbp ? now_ms() : 0;
     c.reap_retired();                                  // (graphs of earlier plans: destroyed under the GPU's work)
+    const double f3 = fbp ? now_ms() : 0;
     HIPCHECK(hipStreamSynchronize(gp.stream));
     const double t4 = now_ms();
+    if (fbp) { g_fbprof[0] += f0 - t3; g_fbprof[1] += f1 - f0; g_fbprof[2] += f2 - f1; g_fbprof[3] += f3 - f2; g_fbprof[4] += t4 - f3; g_fbprof_n++; }
     check_bad(c);
     check_guard(c, gp.stream);
     c.st.error_code = 0;

@@ -18,6 +18,7 @@ struct GraphPack {
     HBuf<double> h_z, h_W, h_state, h_lp, h_dx;
     DBuf<int> d_fa, d_fb;
     DBuf<double> d_z, d_W, d_state, d_lp, d_dx, d_chi2f, d_scalar;
+    DBuf<double> d_lp_last; bool lp_last_valid = false;        // resident loops: the linearisation point of the LAST step enqueued (d_lp itself already holds the next one, UpdArgs::lp_next)
     int F_on_device = 0;               // factors already uploaded
     int dirty_lo = 0, dirty_hi = 0;    // packed factors whose z / W changed since the last upload
     long long content_version = 0;     // bumped whenever z / W of a packed factor changed
@@ -47,7 +48,7 @@ struct GraphPack {
     void release() {
         h_out.release(); mirror_sync = false;
         h_fa.release(); h_fb.release(); h_z.release(); h_W.release(); h_state.release(); h_lp.release(); h_dx.release();
-        d_fa.release(); d_fb.release(); d_z.release(); d_W.release(); d_state.release(); d_lp.release(); d_dx.release();
+        d_fa.release(); d_fb.release(); d_z.release(); d_W.release(); d_state.release(); d_lp.release(); d_lp_last.release(); d_dx.release();
         d_chi2f.release(); d_scalar.release(); h_scalar.release(); h_hostH.release(); d_hostH.release(); d_host_idx.release(); d_upt.release();
         if (stream) { forget_stream(stream); (void)hipStreamDestroy(stream); }
         stream = nullptr;

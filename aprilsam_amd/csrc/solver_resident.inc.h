@@ -14,6 +14,7 @@ static int resident_begin_impl(april_graph_t *g, april_graph_cholesky_param_t *p
     pack_factors(gp, g);
     if (!gp.host_idx.empty()) return -4;          // host-evaluated factors need the host in the loop: use april_graph_cholesky
     pack_states(gp, g, false);
+    gp.lp_last_valid = false;
     orient_asymmetric(c, gp);
     const bool reused = prepare_plan(c, gp, g);
     flush_orientation(c, gp.stream);
@@ -43,8 +44,16 @@ static int resident_steps_impl(april_graph_t *g, april_graph_cholesky_param_t *p
     // every node is re-linearised at the state it has when a batch step begins (aprilsam.c:131-135): once here, and from then on the state
     // update of step i leaves the new states in the l_points as well (UpdArgs::lp_next) -- no 84 KB copy between two steps of the loop
     // (round 5: 0.232 -> 0.225 ms per M3500 iteration)
+    // What the node objects must hold when the loop ends is the linearisation point of the LAST step -- the reference's l_point after K
+    // calls of april_graph_cholesky, the point the factorisation kept for april_graph_cholesky_inc was made at (aprilsam.c:131-135, 508-542) --
+    // and d_lp has moved on by then: one copy per CALL (not per step), before its last step.
     HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
     for (int i = 0; i < n; i++) {
+        if (i == n - 1) {
+            gp.d_lp_last.need((size_t)3 * N);
+            HIPCHECK(hipMemcpyAsync(gp.d_lp_last.p, gp.d_lp.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
+            gp.lp_last_valid = true;
+        }
         if (mode == 1) {
             enqueue_numeric(c, gp, s, nullptr, false, true, false, true);
             HIPCHECK(hipStreamSynchronize(s));
@@ -96,6 +105,9 @@ static int resident_end_impl(april_graph_t *g, april_graph_cholesky_param_t *par
     hipStream_t s = gp.stream;
     const int N = gp.N, F = gp.F;
     HIPCHECK(hipMemcpyAsync(gp.h_state.p, gp.d_state.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
+    // l_point: where the last step was linearised (resident_steps parked it); d_lp follows, so that mirror and device agree again
+    if (gp.lp_last_valid && gp.d_lp_last.cap >= (size_t)3 * N) HIPCHECK(hipMemcpyAsync(gp.d_lp.p, gp.d_lp_last.p, (size_t)24 * N, hipMemcpyDeviceToDevice, s));
+    gp.lp_last_valid = false;
     HIPCHECK(hipMemcpyAsync(gp.h_lp.p, gp.d_lp.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipMemcpyAsync(gp.h_dx.p, gp.d_dx.p, (size_t)24 * N, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
@@ -114,7 +126,7 @@ static int resident_end_impl(april_graph_t *g, april_graph_cholesky_param_t *par
     param->nreordering = N; param->factor_num = gp.Fg;
     c.have_fact = true; c.batch_nodes = N; c.batch_factors = F; c.model.valid = false;
     inc_prepare(c); c.inc_F = F; c.inc_N = N;
-    record_unary_points(gp, 0, F, gp.h_lp.p);                // (unary factors were last linearised at the final l_points)
+    record_unary_points(gp, 0, F, gp.h_lp.p);                // (unary factors were last linearised at the last step's l_points)
     return 0;
 }
 int batch_resident(april_graph_t *g, april_graph_cholesky_param_t *param, int iters, double *chi2_out, double *ms_out) {

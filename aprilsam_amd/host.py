@@ -86,6 +86,9 @@ class SolverLib:
             d.aprilsam_amd_make_lattice.argtypes = [C.POINTER(abi.Graph), C.c_int]
             d.aprilsam_amd_lattice_arrays.argtypes = [C.c_int, _dp, _ip, _ip, _dp, _dp]
             d.aprilsam_amd_graph_from_arrays.argtypes = [C.POINTER(abi.Graph), C.c_int, _dp, C.c_int, _ip, _ip, _dp, _dp]
+            if hasattr(d, "aprilsam_amd_graph_node_arrays"):
+                d.aprilsam_amd_graph_node_arrays.argtypes = [C.POINTER(abi.Graph), _dp, _dp, _dp]
+                d.aprilsam_amd_graph_node_arrays.restype = None
             d.aprilsam_amd_plan_create.restype = C.c_void_p
             d.aprilsam_amd_plan_create.argtypes = [C.c_int, C.c_int, _ip, _dp, C.c_int]
             d.aprilsam_amd_plan_destroy.argtypes = [C.c_void_p]
@@ -306,6 +309,11 @@ class Graph:
     def _gather(self, field):
         n = self.n_nodes
         out = np.empty((n, 3))
+        if self.lib.is_product and hasattr(self.lib.dll, "aprilsam_amd_graph_node_arrays"):      # one call instead of n ctypes round trips
+            k = ("state", "l_point", "delta_X").index(field)
+            args = [None, None, None]; args[k] = _np_d(out)
+            self.lib.dll.aprilsam_amd_graph_node_arrays(self.ptr, *args)
+            return out
         arr = C.cast(self.ptr.contents.nodes.contents.data, C.POINTER(C.POINTER(abi.Node)))
         for i in range(n):
             p = getattr(arr[i].contents, field)

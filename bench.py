@@ -307,6 +307,17 @@ LATTICE1M_CHI2 = [236446240.54074645, 4636226.273819329, 4491095.9102143]      #
 LATTICE100K_CHI2 = [23540091.69690116, 460825.57393385]
 
 
+def normal_eq_check(lib, g, K):
+    """parity property that needs no recorded trace (tests/support/normal_eq.py, a numpy checker pinned on the CPU against the oracle and
+    the unmodified reference): the LAST iteration's dx, as resident_end left it in the node objects next to its linearisation point,
+    against the reference's normal equations (J'WJ + lambda I) dx = J'W r -- outside every timed region"""
+    from tests.support.normal_eq import normal_equation_residual
+    arr = lib.lattice_arrays(K)
+    r = normal_equation_residual(g.l_points(), arr[1], arr[2], arr[3], arr[4], g.deltas(), 1e-4)
+    return {"rel_max": r["rel_max"], "rel_l2": r["rel_l2"], "max_abs_residual": r["max_abs_res"], "max_abs_rhs": r["max_abs_rhs"],
+            "what": "max |(J'WJ + lambda I) dx - J'W r| / max |J'W r| of the last resident iteration, matrix-free in numpy"}
+
+
 def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iters=2):
     """config 5.  world == 1: resident single-GPU iterations.  world > 1: one solve sharded over all ranks."""
     import torch
@@ -336,6 +347,10 @@ def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iter
                    roofline=big_front_rooflines(lp, 2, PMC_TAG + "_pmc_mfma_lattice1m.json"),
                    roofline_hbm=hbm_rooflines(lp, 2, PMC_TAG + "_pmc_hbm_lattice1m.json", survey_assembly_bytes(K * K, nfac - 1, 1)))
         lib.dll.aprilsam_amd_resident_end(g.ptr, p.ptr)
+        try:
+            res["normal_eq"] = normal_eq_check(lib, g, K); res["normal_eq_relres"] = res["normal_eq"]["rel_max"]
+        except Exception as e:
+            res["normal_eq"] = {"error": repr(e)}
     else:
         from aprilsam_amd.shard import ShardedSolver
         sol = ShardedSolver(lib, g, p, rank, world, backend=backend, device=device if backend == "nccl" else None)
@@ -412,7 +427,7 @@ def short_line(out):
     put(cfg, "parity_max_abs_state_err", out.get("parity", {}).get("max_abs_state_err"))
     # ---- config 4 -------------------------------------------------------------------------------------------------------------------
     l100 = out.get("lattice100k", {})
-    for k in ("ms_per_step", "speedup_vs_reference_cpu", "chi2_relerr_vs_reference", "factor_tflops", "error"):
+    for k in ("ms_per_step", "speedup_vs_reference_cpu", "chi2_relerr_vs_reference", "normal_eq_relres", "factor_tflops", "error"):
         if k in l100:
             put(cfg, f"lattice100k_{k}", l100[k])
     rc = l100.get("reference_cpu_same_host")
@@ -420,7 +435,7 @@ def short_line(out):
         put(cfg, "lattice100k_reference_cpu_s_per_iter", rc.get("s_per_iter"))
     # ---- config 5 -------------------------------------------------------------------------------------------------------------------
     l1m = out.get("lattice1m", {})
-    for k in ("ms_per_step", "n_gpus", "factor_tflops", "comm_bytes_per_iteration", "error"):
+    for k in ("ms_per_step", "n_gpus", "factor_tflops", "normal_eq_relres", "comm_bytes_per_iteration", "error"):
         if k in l1m:
             put(cfg, f"lattice1m_{k}", l1m[k])
     for k in ("chi2_relerr_vs_single_gpu", "chi2_relerr_vs_reference"):      # (K = 1000: the recorded single-GPU trace; K = 316: the reference's own chi^2)
@@ -655,6 +670,10 @@ def main():
                 "roofline_hbm": hbm_rooflines(lp, 3, PMC_TAG + "_pmc_hbm_lattice100k.json", survey_assembly_bytes(316 * 316, len(arr[1]) - 1, 1)),
             }
             lib.dll.aprilsam_amd_resident_end(g.ptr, p.ptr)
+            try:
+                out["lattice100k"]["normal_eq"] = normal_eq_check(lib, g, 316); out["lattice100k"]["normal_eq_relres"] = out["lattice100k"]["normal_eq"]["rel_max"]
+            except Exception as e:
+                out["lattice100k"]["normal_eq"] = {"error": repr(e)}
             p.destroy(); g.destroy()
             # the reference on the same lattice on THIS host: measured when asked for (--cpu-lattice100k, one call = one iteration,
             # about a minute), otherwise the figure recorded by such a run on the GPU box (profiles/, same hardware class)

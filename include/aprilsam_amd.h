@@ -487,6 +487,10 @@ int aprilsam_amd_lattice_arrays(int K, double *states, int *fa, int *fb, double 
 void aprilsam_amd_graph_from_arrays(april_graph_t *graph, int N, const double *states, int F, const int *fa,
                                     const int *fb, const double *z, const double *W);
 
+/* Bulk read of the node objects: state / l_point / delta_X of every node (3 doubles each, node order; any destination may
+ * be NULL).  Assumes xyt nodes (3 degrees of freedom), like the two calls above. */
+void aprilsam_amd_graph_node_arrays(const april_graph_t *graph, double *state, double *l_point, double *delta_X);
+
 /* Stage-level parity exports (tests/test_gpu_stages.py): the device linearisation and the gather assembly seen in the
  * caller's node coordinates, at the graph's current states (l_point <- state first, as a batch step does).
  *   what 0: out[33 * F], per factor (J_a^T W) J_a, (J_a^T W) J_b, (J_b^T W) J_b (3 x 3 row-major each), (J_a^T W) r, (J_b^T W) r
