@@ -31,7 +31,7 @@ struct Options {
     int small_threads = 1024;     // workgroup size of k_front_small (256 / 512 / 1024) on latency-bound levels ...
     int tp_threads = 512;         // ... and on throughput levels (>= tp_fronts fronts)
     int tp_fronts = 1000;         // levels with at least this many fronts are "throughput levels" ...
-    int tp_lds_kb = 64;           // ... where only fronts up to this LDS size run fully in LDS (the rest: panel mode, more workgroups per CU)
+    int tp_lds_kb = 80;           // ... where only fronts up to this LDS size run fully in LDS (the rest: panel mode, more workgroups per CU).  80 KB = two such workgroups per compute unit; measured, round 6, k_front_small ms per iteration at 48 / 64 / 80 / 96 / 160: 100 k lattice 0.976 / 0.936-0.955 / 0.924-0.936 / 1.174 / 1.100, 1 M lattice 8.65 / 8.22-8.36 / 7.94-8.05 / 10.98 / 10.59
     int amalg = 0;                // 1 = separator amalgamation (symbolic.cpp: amalgamate): separator fronts take in child separators where a cost model of the critical path (hand-over per front vs pivot chain per column) says so -- fewer dependent levels on graphs the size of M3500
     int amalg_max = 64;           // ... as long as the merged front owns at most this many poses
     int pin_last = 0;             // nested dissection keeps the pin_last newest poses out of the dissection: they form the root front ("recent poses last")

@@ -315,7 +315,7 @@ def normal_eq_check(lib, g, K):
     arr = lib.lattice_arrays(K)
     r = normal_equation_residual(g.l_points(), arr[1], arr[2], arr[3], arr[4], g.deltas(), 1e-4)
     return {"rel_max": r["rel_max"], "rel_l2": r["rel_l2"], "max_abs_residual": r["max_abs_res"], "max_abs_rhs": r["max_abs_rhs"],
-            "what": "max |(J'WJ + lambda I) dx - J'W r| / max |J'W r| of the last resident iteration, matrix-free in numpy"}
+            "what": "max |(J'WJ + lambda I) dx - J'W r| / max_i sum_f |J_f'W_f r_f|_i of the last resident iteration, matrix-free in numpy"}
 
 
 def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iters=2):

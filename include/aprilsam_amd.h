@@ -280,7 +280,7 @@ void aprilsam_amd_clear_error(void);
  *                       path (default 156; 0 forces the multi-workgroup path everywhere)
  *   "panel_mode"        0 = no panel mode (fronts that do not fit LDS entirely go to the multi-workgroup path) (1)
  *   "tp_fronts", "tp_lds_kb"  levels with at least tp_fronts fronts (default 1000) are throughput-bound: there only
- *                       fronts up to tp_lds_kb KiB (default 64) run fully in LDS, larger ones use panel mode so that
+ *                       fronts up to tp_lds_kb KiB (default 80: two workgroups per compute unit) run fully in LDS, larger ones use panel mode so that
  *                       several workgroups share a compute unit
  *   "small_threads", "tp_threads"  workgroup size of the single-workgroup front kernel (256 / 512 / 1024) on
  *                       latency-bound levels (default 1024) and on throughput levels (default 512)

@@ -8,7 +8,8 @@ and the dx the solver returned,
 
 with J_f, r_f the Jacobians / residual of factor f at lp (april_graph_xyt.c:62-124 for xyt, april_graph_xytpos.c:63-102 for
 the prior) -- the system the reference assembles and solves.  A correct dx leaves |res| at rounding level relative to
-|J^T W r|; a wrong pivot, a lost update block or a stale front leaves it at order one.  Cost O(F): usable at the full sizes
+the terms of J^T W r (their sum without cancellation: near convergence J^T W r itself goes to zero); a wrong pivot, a lost
+update block or a stale front leaves it at order one.  Cost O(F): usable at the full sizes
 of BASELINE.json's configs 4 and 5 (10^5 and 10^6 poses), where the reference itself cannot run.
 
 Valid for information matrices that are symmetric as given (with an asymmetric W the reference's system depends on its own
@@ -52,14 +53,15 @@ def linearise(lp, fa, fb, z):
 
 
 def normal_equation_residual(lp, fa, fb, z, W, dx, lam=0.0, lam_nodes=None, chunk=1 << 20):
-    """-> dict(max_abs_res, max_abs_rhs, rel_max, rel_l2): residual of (J'WJ + lam I) dx = J'W r at lp.
+    """-> dict(max_abs_res, max_abs_rhs, max_rhs_terms, rel_max, rel_l2): residual of (J'WJ + lam I) dx = J'W r at lp, relative to
+    the size of the right-hand side's terms (max over components of sum_f |J_f' W_f r_f|).
     lam_nodes: number of leading nodes that carry the Tikhonov term (all by default; the incremental path puts it only on the
     poses present at the last batch step, aprilsam.c:197-204 vs :508-542).  Works through the factors in chunks (memory)."""
     lp = np.asarray(lp, float).reshape(-1, 3); dx = np.asarray(dx, float).reshape(-1, 3)
     fa = np.asarray(fa, np.int64); fb = np.asarray(fb, np.int64)
     z = np.asarray(z, float).reshape(-1, 3); W = np.asarray(W, float).reshape(-1, 3, 3)
     N, F = len(lp), len(fa)
-    res = np.zeros((N, 3)); rhs = np.zeros((N, 3))
+    res = np.zeros((N, 3)); rhs = np.zeros((N, 3)); scale = np.zeros((N, 3))
     for f0 in range(0, F, chunk):
         s = slice(f0, min(F, f0 + chunk))
         a, b = fa[s], fb[s]
@@ -73,9 +75,12 @@ def normal_equation_residual(lp, fa, fb, z, W, dx, lam=0.0, lam_nodes=None, chun
         for k in range(3):
             res[:, k] += np.bincount(a, weights=ga[:, k], minlength=N) + np.bincount(bb, weights=gb[:, k] * binary, minlength=N)
             rhs[:, k] += np.bincount(a, weights=ha[:, k], minlength=N) + np.bincount(bb, weights=hb[:, k] * binary, minlength=N)
+            scale[:, k] += np.bincount(a, weights=np.abs(ha[:, k]), minlength=N) + np.bincount(bb, weights=np.abs(hb[:, k]) * binary, minlength=N)
     if lam > 0:
         n = N if lam_nodes is None else lam_nodes
         res[:n] += lam * dx[:n]
-    mr, mb = float(np.max(np.abs(res))), float(np.max(np.abs(rhs)))
-    return dict(max_abs_res=mr, max_abs_rhs=mb, rel_max=mr / mb if mb > 0 else mr,
-                rel_l2=float(np.linalg.norm(res) / max(np.linalg.norm(rhs), 1e-300)))
+    # scale: sum_f |J_f' W_f r_f| per component, the terms of the right-hand side WITHOUT their cancellation -- near convergence J'W r
+    # itself tends to zero while the rounding of its evaluation (here, and in any solver) stays at eps times these terms
+    mr, mb, ms = float(np.max(np.abs(res))), float(np.max(np.abs(rhs))), float(np.max(scale))
+    return dict(max_abs_res=mr, max_abs_rhs=mb, max_rhs_terms=ms, rel_max=mr / ms if ms > 0 else mr,
+                rel_l2=float(np.linalg.norm(res) / max(np.linalg.norm(scale), 1e-300)))

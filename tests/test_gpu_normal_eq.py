@@ -11,7 +11,7 @@ from tests.support.normal_eq import normal_equation_residual
 
 pytestmark = pytest.mark.gpu
 LAM = 1e-4
-RES_RTOL = 1e-9          # observed: 1e-13 .. 1e-11
+RES_RTOL = 1e-10         # observed: 1e-14 .. 4e-12 (the reference itself: 2e-15, tests/test_normal_eq.py)
 
 
 def _check_api_steps(lib, arr, iters):
