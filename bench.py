@@ -107,7 +107,9 @@ def hbm_rooflines(prof, iters, pmc_file=None, survey_bytes=None):
     counter passes of the same workload"""
     pmc, src = load_pmc(pmc_file) if pmc_file else (None, "not collected")
     out = []
-    for name in ("k_linearize", "k_assemble_big", "k_backsolve"):
+    # (k_front_small appears under both bounds: on the lattices' throughput levels -- thousands of leaves -- it streams the fronts through
+    # HBM, near the top of a tree it is a latency chain; its bytes: each small front's L panel + update block once)
+    for name in ("k_linearize", "k_assemble_big", "k_backsolve", "k_front_small"):
         k = next((q for q in prof if q["name"] == name), None)
         if not k or k["ms"] <= 0 or k["bytes"] <= 0:
             continue
@@ -473,6 +475,8 @@ def short_line(out):
     for tag, blk in (("l100k", l100), ("l1m", l1m)):
         for r in (blk.get("roofline") or []) + (blk.get("roofline_hbm") or []):
             kn = r.get("kernel")
+            if kn == "k_front_small" and r.get("bound") == "hbm":
+                kn = "k_front_small_hbm"
             for k in ("frac", "traffic_over_algorithmic"):
                 if k in r and scalar(r[k]):
                     roof[f"{tag}_{kn}_{k}"] = sig(r[k], 4)
