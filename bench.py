@@ -360,6 +360,21 @@ def lattice1m(lib, rank, world, device, backend, barrier, sync_all, K=1000, iter
         chi = [sol.chi2()]
         sol.iterate(1)                                  # first iteration: also opens the point-to-point channels
         chi.append(sol.chi2())
+        # parity that needs no recorded trace (normal_eq_check above): the first iteration's dx = gathered states - initial states against the
+        # reference's normal equations at the initial states.  The gather is a collective of the library (every rank takes part); the numpy
+        # part runs on rank 0, outside the timed region
+        st1 = sol.gather_states()
+        if rank == 0:
+            try:
+                from tests.support.normal_eq import normal_equation_residual
+                arr = lib.lattice_arrays(K)
+                dx1 = st1 - arr[0]
+                dx1[:, 2] = (dx1[:, 2] + np.pi) % (2 * np.pi) - np.pi
+                r = normal_equation_residual(arr[0], arr[1], arr[2], arr[3], arr[4], dx1, 1e-4)
+                res["normal_eq"] = {"rel_max": r["rel_max"], "rel_l2": r["rel_l2"], "what": "first sharded iteration: dx = gathered states - initial states"}
+                res["normal_eq_relres"] = r["rel_max"]
+            except Exception as e:
+                res["normal_eq"] = {"error": repr(e)}
         barrier(); torch.cuda.synchronize()
         t1 = time.perf_counter()
         sol.iterate(iters)                              # one library call: kernels and exchange on the solver stream

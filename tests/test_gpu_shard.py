@@ -127,6 +127,18 @@ def test_sharded_1m_lattice_matches_the_single_gpu_trace(built, lib, world):
     want = np.array(bench.LATTICE1M_CHI2[:2])
     assert np.max(np.abs(c1 - want) / want) < 1e-9
     _check(res, st, world, want, s1)
+    _normal_equations_hold(lib, 1000, st)
+
+
+def _normal_equations_hold(lib, K, st_after_one_iteration):
+    """... and against nothing but the inputs: dx = gathered states - initial states (theta wrapped) solves the reference's normal equations
+    at the initial states (tests/support/normal_eq.py; the subtraction costs eps x |coordinate| ~ 1e-13 of dx)"""
+    from tests.support.normal_eq import normal_equation_residual
+    arr = lib.lattice_arrays(K)
+    dx = st_after_one_iteration - arr[0]
+    dx[:, 2] = (dx[:, 2] + np.pi) % (2 * np.pi) - np.pi
+    out = normal_equation_residual(arr[0], arr[1], arr[2], arr[3], arr[4], dx, 1e-4)
+    assert out["rel_max"] < 1e-9, out
 
 
 def test_rccl_unavailable_on_one_rank_falls_back_to_host_callbacks_everywhere(built, lib):
