@@ -379,7 +379,9 @@ int aprilsam_amd_batch_resident(april_graph_t *graph, april_graph_cholesky_param
  * steps(n, mode) enqueues n Gauss-Newton iterations on the solver's HIP stream — mode 0 asynchronously
  * (hipGraph replay), mode 1 with every kernel launch bracketed by a HIP event pair on that stream and a
  * synchronisation per iteration; sync waits and returns -2 if a pivot was not positive; chi2 evaluates
- * chi^2 of the resident states; end writes the states back into the graph's node objects. */
+ * chi^2 of the resident states; end leaves the node objects as the same number of april_graph_cholesky calls would
+ * (aprilsam.c:131-135, 311-315): state = the final state, l_point = the point the LAST step was linearised at,
+ * delta_X = that step's dx -- the factorisation of that step is kept, so april_graph_cholesky_inc may follow. */
 int    aprilsam_amd_resident_begin(april_graph_t *graph, april_graph_cholesky_param_t *param);
 int    aprilsam_amd_resident_steps(april_graph_t *graph, april_graph_cholesky_param_t *param, int n, int mode);
 int    aprilsam_amd_resident_sync(april_graph_t *graph, april_graph_cholesky_param_t *param);
