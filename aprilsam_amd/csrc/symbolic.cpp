@@ -266,8 +266,15 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
     });
     if (lost.load() >= 0) fail(ERR_INTERNAL, "factor %d not inside its front", lost.load());
     for (int f = 0; f < F; f++) if (P.fac_front[f] >= 0 && P.fac_lb[f] >= 0) P.fac_swap[f] = P.fac_la[f] < P.fac_lb[f];
-    if ((size_t)3 * F >= (1u << 26)) fail(ERR_UNSUPPORTED, "%d factors: this build handles up to %u (packed sort keys of the symbolic analysis)", F, (1u << 26) / 3 - 1);
-    static_assert(sizeof(unsigned long long) == 8, "packed sort keys");
+    // packed sort keys below: 16 bits of local block column, 17 of local block row + 1, 30 of contribution id, 1 of kind.  (Round 6: the id had
+    // 26 bits -- 22 million factors -- which a 2 500 x 2 500 lattice exceeds while its 190 GB of fronts still fit one MI355X.)
+    constexpr int KEY_SRC_BITS = 30, KEY_ROW_BITS = 17, KEY_COL_BITS = 16;
+    static_assert(1 + KEY_SRC_BITS + KEY_ROW_BITS + KEY_COL_BITS == 64 && sizeof(unsigned long long) == 8, "packed sort keys");
+    if ((size_t)3 * F >= (1u << KEY_SRC_BITS) || (size_t)5 * F >= 0x7fffffffu)
+        fail(ERR_UNSUPPORTED, "%d factors: this build handles up to %u (packed sort keys of the symbolic analysis)", F, (1u << KEY_SRC_BITS) / 3 - 1);
+    for (int t = 0; t < nT; t++)
+        if (P.f_nsb[t] + P.f_nub[t] + 1 >= (1 << KEY_COL_BITS))
+            fail(ERR_UNSUPPORTED, "front %d has %d block rows: this build handles up to %d (packed sort keys of the symbolic analysis)", t, P.f_nsb[t] + P.f_nub[t] + 1, (1 << KEY_COL_BITS) - 1);
     P.bd_front_ptr.clear(); P.rd_front_ptr.clear();       // (the per-kind gather lists are derived on demand: build_gather_lists)
 
     stamp();
@@ -283,7 +290,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
         const size_t total = (size_t)ptr[nT];
         std::vector<unsigned long long> key(total);
         auto pack = [](int col, int row, int src, int rhs) {
-            return ((unsigned long long)(unsigned)col << 45) | ((unsigned long long)(unsigned)(row + 1) << 27) | ((unsigned long long)(unsigned)src << 1) | (unsigned)rhs;
+            return ((unsigned long long)(unsigned)col << (1 + KEY_SRC_BITS + KEY_ROW_BITS)) | ((unsigned long long)(unsigned)(row + 1) << (1 + KEY_SRC_BITS)) | ((unsigned long long)(unsigned)src << 1) | (unsigned)rhs;
         };
         {
             std::vector<int> fill(ptr.begin(), ptr.end() - 1);
@@ -298,7 +305,7 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
                 }
             }
         }
-        auto same_dest = [](unsigned long long a, unsigned long long b) { return (a >> 27) == (b >> 27); };     // same (col, row)
+        auto same_dest = [](unsigned long long a, unsigned long long b) { return (a >> (1 + KEY_SRC_BITS)) == (b >> (1 + KEY_SRC_BITS)); };     // same (col, row)
         P.dest_front_ptr.assign(nT + 1, 0);
         plan_parallel_for(nT, 64, [&](int t0, int t1) {
             for (int t = t0; t < t1; t++) {
@@ -316,7 +323,8 @@ void build_plan(Plan &P, int N, int F, const int *fn, const double *xy, int leaf
                 int d = P.dest_front_ptr[t] - 1;
                 for (int i = ptr[t]; i < ptr[t + 1]; i++) {
                     const unsigned long long k = key[i];
-                    const int col = (int)(k >> 45), row = (int)((k >> 27) & 0x3ffff) - 1, src = (int)((k >> 1) & 0x3ffffff), rhs = (int)(k & 1);
+                    const int col = (int)(k >> (1 + KEY_SRC_BITS + KEY_ROW_BITS)), row = (int)((k >> (1 + KEY_SRC_BITS)) & ((1u << KEY_ROW_BITS) - 1)) - 1,
+                              src = (int)((k >> 1) & ((1u << KEY_SRC_BITS) - 1)), rhs = (int)(k & 1);
                     if (i == ptr[t] || !same_dest(k, key[i - 1])) P.dest[++d] = { row, col, i, i };
                     P.dest[d].src_end = i + 1;
                     (rhs ? P.slot_rhs : P.slot_blk)[src] = i;
