@@ -30,6 +30,7 @@ void april_graph_cholesky_param_init(april_graph_cholesky_param_t *param) {
     memset(param, 0, sizeof(*param));
     param->tikhanov = 0.0001;
     param->nreordering = 1;
+    asam::warm_up();                           // once per process: the HIP runtime's lazy initialisations happen here, not inside the first solver calls
 }
 
 // replaces aprilsam.c:66-85 — frees the owned arrays and param itself (the caller heap-allocates it)

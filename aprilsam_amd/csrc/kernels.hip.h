@@ -22,7 +22,7 @@
 //   k_backsolve_gemv / k_backsolve_t   the same for all other fronts, 32 columns at a time, level by level
 //   k_update_states    state = l_point + dx, theta wrap, NaN guard (april_graph_xyt.c:302-314); on the batch path this
 //                      rides on the back substitution (backsolve_finish)
-//   k_chi2 / k_reduce  chi^2 with the 1/2-on-xyt convention (april_graph.c:79-98), deterministic sum
+//   k_chi2 / k_reduce (+ k_reduce_parts)  chi^2 with the 1/2-on-xyt convention (april_graph.c:79-98), deterministic sum
 //   k_scatter_host     blocks of host-evaluated (foreign-type) factors into the contribution slots
 //   k_pack_update      packed Schur update of a front for the multi-GPU exchange
 //   k_inc_prologue / k_inc_one / front_update_body   the incremental path: patches + linearisation of the new factors, a whole small
@@ -495,6 +495,24 @@ __global__ void __launch_bounds__(1024) k_reduce(int n, const double *__restrict
         __syncthreads();
     }
     if (threadIdx.x == 0) out[0] = s[0];
+}
+// ... of MANY doubles (the 10^6-pose lattice has 3 x 10^6 factors: one workgroup read them at 19 GB/s, 1.3 ms -- fifteen times k_chi2 itself):
+// REDUCE_PARTS workgroups sum one contiguous chunk each into parts[], k_reduce adds the parts.  The chunks and both trees depend on n alone, so the
+// sum is as reproducible as the one-stage form; sums of at most REDUCE_SPLIT terms keep that form (and their bits: M3500, the incremental demo).
+constexpr int REDUCE_SPLIT = 1 << 16, REDUCE_PARTS = 1024;
+__global__ void __launch_bounds__(TPB) k_reduce_parts(int n, const double *__restrict__ in, double *__restrict__ parts) {
+    __shared__ double s[TPB];
+    const int chunk = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int i0 = (int)blockIdx.x * chunk, i1 = min(n, i0 + chunk);
+    double acc = 0;
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += TPB) acc += in[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = TPB / 2; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) s[threadIdx.x] += s[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) parts[blockIdx.x] = s[0];
 }
 
 // ------------------------------------------------------------------------------------------------------

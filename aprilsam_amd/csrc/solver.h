@@ -23,6 +23,7 @@ struct Options {
     int inc_replan_tall = 1;      // ... and when a front of an all-single-workgroup plan outgrows the LDS (rows collected from loop closures), the step re-plans instead of taking the multi-launch path from then on
     int inc_update = 1;           // ... and the fronts on the root path of a loop closure take a low-rank UPDATE of their factor (front_update_body) instead of being re-assembled and re-factorised
     int speculate_factors = 1;    // warm batch calls: the pass over the factor objects (edits in place) runs under the GPU's work on the packed copies; an edit voids the run
+    int warm_up = 1;              // april_graph_cholesky_param_init initialises the HIP runtime's lazy parts once per process (a stream, the copy engines' queues, the code object, the graph machinery) instead of the first solver calls; 0 = leave them lazy (APRILSAM_AMD_WARM_UP=0: the option is read from the environment before the first param exists)
     int syrk_xcd_order = 512;     // wide trailing updates of at least this many tiles (one round of workgroups is 512): tile order in which every XCD works on 8 x 8 blocks of tiles (kernels.hip.h: trapezoid_tile_xcd); 0 = never
     int syrk_small_tiles = 320;   // wide trailing updates of fewer 64 x 64 tiles than this (a quarter of a round of workgroups) use 32 x 32 tiles; 0 = never.  Measured on the 100 k lattice: k_syrk_big 0.664 (never) / 0.633 (320) / 0.648 (640) / 0.676 (1280) ms -- such a launch is 27 us of start / end latencies whatever its tiles
     int syrk_pair_tiles = 2048;   // big fronts: levels whose first wide update has at least this many 64 x 64 tiles close every PAIR of outer blocks with one K = 256 update (after the first block of a pair only the next block's columns are updated); 0 = never.  Smaller updates are a launch's worth of latency whatever their K: pairs only add a launch there
@@ -88,6 +89,7 @@ int api_set_device(int d);
 int api_param_set_device(const april_graph_cholesky_param_t *param, int slot);
 int api_param_get_device(const april_graph_cholesky_param_t *param);
 void unbind_param(const april_graph_cholesky_param_t *param);
+void warm_up() noexcept;          // once per process, from april_graph_cholesky_param_init: see solver.hip.cpp
 int api_set_option(const char *name, double v);
 int api_get_option(const char *name, double *v);
 

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -67,7 +68,7 @@ static const OptionDef OPTION_TABLE[] = {
     { "inc_one_threads", &Options::inc_one_threads, 64, true }, { "inc_one_spin", &Options::inc_one_spin, 0, true }, { "inc_tail", &Options::inc_tail, 0, false },
     { "inc_inline", &Options::inc_inline, 0, true }, { "inc_update", &Options::inc_update, 0, true }, { "inc_tail_solve", &Options::inc_tail_solve, 0, true },
     { "inc_lazy_states", &Options::inc_lazy_states, 0, true }, { "inc_replan_tall", &Options::inc_replan_tall, 0, true },
-    { "speculate_factors", &Options::speculate_factors, 0, true }, { "pin_last", &Options::pin_last, 0, false }, { "persist", &Options::persist, 0, false },
+    { "speculate_factors", &Options::speculate_factors, 0, true }, { "warm_up", &Options::warm_up, 0, true }, { "pin_last", &Options::pin_last, 0, false }, { "persist", &Options::persist, 0, false },
     { "persist_max_fronts", &Options::persist_max_fronts, 0, false }, { "linearize_staged_min", &Options::linearize_staged_min, 0, false },
     { "wave_backsolve", &Options::wave_backsolve, 0, false }, { "blk_backsolve", &Options::blk_backsolve, 0, false }, { "tail_poses", &Options::tail_poses, 8, false },
     { "batch_extend", &Options::batch_extend, 0, true }, { "extend_tail_fronts", &Options::extend_tail_fronts, 0, true }, { "mem_cap_mb", &Options::mem_cap_mb, 0, true },
@@ -122,6 +123,7 @@ template <class V> struct Registry {             // std::map: iterators and elem
     void erase(typename Map::iterator it) { std::lock_guard<std::mutex> lk(mu); m.erase(it); }
     void put(const void *k, std::unique_ptr<V> v) { std::lock_guard<std::mutex> lk(mu); m[k] = std::move(v); }
     template <class F> void for_each(F &&f) { std::lock_guard<std::mutex> lk(mu); for (auto &kv : m) f(*kv.second); }
+    template <class F> bool with(const void *k, F &&f) { std::lock_guard<std::mutex> lk(mu); auto it = m.find(k); if (it == m.end()) return false; f(*it->second); return true; }     // (the element cannot be erased while f looks at it)
 };
 static std::map<const void *, int> g_param_slot; static std::mutex g_param_slot_mu;      // aprilsam_amd_param_set_device
 static std::atomic<int> g_param_slot_n{ 0 };      // bound params (zero: every call takes the default slot without looking)
@@ -135,6 +137,9 @@ static int slot_for(const void *param, const void *g) {
 struct SlotLock {
     int slot; std::unique_lock<std::mutex> lk;
     SlotLock(const void *param, const void *g) : slot(slot_for(param, g)), lk(g_slot_mu[slot]) {
+        // (a call found by its graph alone -- april_graph_chi2, a graph being destroyed -- read the pack's slot before it held the lock: the
+        // pack may have moved to another slot in between, pack_for below; look again under the lock)
+        for (int now; (now = slot_for(param, g)) != slot; ) { lk.unlock(); slot = now; lk = std::unique_lock<std::mutex>(g_slot_mu[slot]); }
         t_slot = slot;
         if (device_count() > 0) {
             const int dev = physical_device(slot);
@@ -233,6 +238,68 @@ struct PatchList {
 #include "solver_calls.inc.h"
 #include "solver_resident.inc.h"
 #include "solver_shard.inc.h"
+
+// ------------------------------------------------------------------------------------------------------
+// Runtime warm-up, once per process, from april_graph_cholesky_param_init (the API's set-up call; aprilsam.c:45-64 has nothing to set up).
+// What the HIP runtime initialises lazily would otherwise land inside the first solver calls -- measured with rocprofv3 --hip-trace on the
+// incremental demo: a stream 8-20 ms (each of the first two), the first host-to-device and the first device-to-host copy 7 ms each (the latter not before the first
+// re-planned incremental step, 1 330 steps into the run), the first hipFuncSetAttribute (the code object) 2 ms, the first
+// hipGraphInstantiate 8 ms.  Option warm_up = 0 leaves everything lazy.  Never fails: without a device, or on any error, it does nothing.
+// ------------------------------------------------------------------------------------------------------
+static std::once_flag g_warm_once;
+void warm_up() noexcept {
+    std::call_once(g_warm_once, [] {
+        try {
+            load_env_options();
+            if (!g_opt.warm_up || device_count() <= 0) return;
+            ensure_device();
+            SlotLock lk(nullptr, nullptr);
+            hipStream_t s = take_stream(t_slot), s2 = take_stream(t_slot);      // two: a graph owns its stream, and a program's second graph paid 10 ms for the second hardware queue inside its first solver call
+            // copies of a size that takes the copy engines' path (small ones are done by a shader), in every direction the solver uses,
+            // from pinned and from pageable host memory (the latter allocates the runtime's staging buffers)
+            constexpr size_t WB = 4 << 20;
+            char *d = nullptr, *h = nullptr;
+            std::vector<char> pageable(WB, 0);
+            if (hipMalloc((void **)&d, 2 * WB) == hipSuccess && hipHostMalloc((void **)&h, WB, hipHostMallocDefault) == hipSuccess) {
+                memset(h, 0, WB);
+                // (several sizes: the runtime copies small, medium and large blocks by different means -- inline, through staging buffers it
+                // allocates on first use, by pinning the caller's pages -- and each of them has a first time)
+                set_small_attr();
+                auto kernel = [&] { hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, 1, (const double *)d, (double *)d + 8); };
+                for (size_t nb : { (size_t)8 << 10, (size_t)32 << 10, (size_t)512 << 10, WB }) {
+                    // ... each of them on an idle stream and behind a kernel that is still in flight (the runtime picks its means by that, too;
+                    // the 7.6 ms of the demo's step 1 330 were a device-to-host copy's first time on one of these paths)
+                    for (int busy = 0; busy < 2; busy++) {
+                        auto before = [&] { if (busy) kernel(); else (void)hipStreamSynchronize(s); };
+                        before(); (void)hipMemcpyAsync(d, h, nb, hipMemcpyHostToDevice, s);
+                        before(); (void)hipMemcpyAsync(h, d, nb, hipMemcpyDeviceToHost, s);
+                        before(); (void)hipMemcpyAsync(d + WB, d, nb, hipMemcpyDeviceToDevice, s);
+                        before(); (void)hipMemcpyAsync(d, pageable.data(), nb, hipMemcpyHostToDevice, s);
+                        before(); (void)hipMemcpyAsync(pageable.data(), d, nb, hipMemcpyDeviceToHost, s);
+                    }
+                }
+                kernel(); (void)hipMemsetAsync(d, 0, WB, s);
+                (void)hipStreamSynchronize(s);
+                kernel();
+                hipGraph_t graph = nullptr; hipGraphExec_t ge = nullptr;
+                if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, 1, (const double *)d, (double *)d + 8);
+                    if (hipStreamEndCapture(s, &graph) == hipSuccess && graph) {
+                        if (hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0) == hipSuccess && ge) (void)hipGraphLaunch(ge, s);
+                        (void)hipGraphDestroy(graph);
+                    }
+                }
+                (void)hipStreamSynchronize(s);
+                if (ge) (void)hipGraphExecDestroy(ge);
+            }
+            if (d) (void)hipFree(d);
+            if (h) (void)hipHostFree(h);
+            if (s2) park_stream(t_slot, s2);
+            park_stream(t_slot, s);
+        } catch (...) {}
+        (void)hipGetLastError();
+    });
+}
 
 // ------------------------------------------------------------------------------------------------------
 // Host-side consistency checks of the index arithmetic that host launch tables and device kernels share

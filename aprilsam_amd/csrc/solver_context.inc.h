@@ -882,7 +882,11 @@ static double device_chi2(GraphPack &gp) {     // chi^2 at d_state; synchronises
     hipStream_t s = gp.stream;
     if (gp.F == 0) return 0;
     hipLaunchKernelGGL(k_chi2, dim3((gp.F + TPB - 1) / TPB), dim3(TPB), 0, s, gp.F, gp.d_fa.p, gp.d_fb.p, gp.d_z.p, gp.d_W.p, gp.d_state.p, gp.d_chi2f.p);
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, gp.F, gp.d_chi2f.p, gp.d_scalar.p);
+    if (gp.F > REDUCE_SPLIT) {         // (the parts live behind the F_cap per-factor terms: upload_factors)
+        double *parts = gp.d_chi2f.p + gp.F_cap;
+        hipLaunchKernelGGL(k_reduce_parts, dim3(REDUCE_PARTS), dim3(TPB), 0, s, gp.F, gp.d_chi2f.p, parts);
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, REDUCE_PARTS, parts, gp.d_scalar.p);
+    } else hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, gp.F, gp.d_chi2f.p, gp.d_scalar.p);
     HIPCHECK(hipMemcpyAsync(gp.h_scalar.p, gp.d_scalar.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHECK(hipStreamSynchronize(s));
     return gp.h_scalar.p[0];

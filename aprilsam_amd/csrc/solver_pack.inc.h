@@ -5,6 +5,31 @@
 // ------------------------------------------------------------------------------------------------------
 static std::atomic<long long> g_pack_serial{ 0 };
 static void forget_stream(hipStream_t s);      // solver_context.inc.h: no context may record an event on a stream that is about to be destroyed
+// Streams are recycled per device slot.  On this runtime hipStreamCreateWithFlags takes 8 ms (a hardware queue) and hipStreamDestroy 2 ms
+// (rocprofv3 --hip-trace, round 6): a graph's first solver call paid the former, its destruction the latter -- a program that builds a
+// graph per solve (tools/soak_batch.py; a front end that re-creates its graph) paid both every time.  A released pack parks its idle
+// stream; the next pack of that slot takes it.
+constexpr int STREAM_POOL_MAX = 4;
+static std::mutex g_stream_pool_mu;
+static std::vector<hipStream_t> g_stream_pool[MAX_SLOTS];
+static hipStream_t take_stream(int slot) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        auto &v = g_stream_pool[slot];
+        if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+    }
+    hipStream_t s = nullptr;
+    HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+static void park_stream(int slot, hipStream_t s) {
+    if (hipStreamSynchronize(s) == hipSuccess) {          // (idle, and healthy: a stream that reports an error is not handed on)
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        auto &v = g_stream_pool[slot];
+        if ((int)v.size() < STREAM_POOL_MAX) { v.push_back(s); return; }
+    } else (void)hipGetLastError();
+    (void)hipStreamDestroy(s);
+}
 struct GraphPack {
     int slot = 0;                      // device slot the pack's buffers and stream live on (solver.hip.cpp: SlotLock)
     const long long serial = ++g_pack_serial;      // captured hipGraphs are keyed by it: a pack freed and another allocated at the same addresses must not match
@@ -50,7 +75,7 @@ struct GraphPack {
         h_fa.release(); h_fb.release(); h_z.release(); h_W.release(); h_state.release(); h_lp.release(); h_dx.release();
         d_fa.release(); d_fb.release(); d_z.release(); d_W.release(); d_state.release(); d_lp.release(); d_lp_last.release(); d_dx.release();
         d_chi2f.release(); d_scalar.release(); h_scalar.release(); h_hostH.release(); d_hostH.release(); d_host_idx.release(); d_upt.release();
-        if (stream) { forget_stream(stream); (void)hipStreamDestroy(stream); }
+        if (stream) { forget_stream(stream); park_stream(slot, stream); }
         stream = nullptr;
     }
 };
@@ -58,18 +83,34 @@ struct GraphPack {
 static Registry<GraphPack> g_packs;
 
 static int slot_of_graph(const void *g) {
-    auto it = g_packs.find(g);
-    return it == g_packs.end() ? -1 : it->second->slot;
+    int slot = -1;
+    g_packs.with(g, [&](GraphPack &gp) { slot = gp.slot; });
+    return slot;
 }
 // the pack of a graph, on the slot of the call in progress (a pack left behind on another slot by an earlier call moves: dropped there,
 // rebuilt here -- one graph is driven from one slot at a time)
 static GraphPack &pack_for(const april_graph_t *g) {
     auto it = g_packs.find(g);
-    if (it != g_packs.end() && it->second->slot != t_slot) { it->second->release(); g_packs.erase(it); it = g_packs.end(); }
+    if (it != g_packs.end() && it->second->slot != t_slot) {
+        // The pack is released under the OLD slot's lock as well, so that no call on that slot is inside it (april_graph_chi2 or a destroy
+        // found by the graph alone).  That lock is tried, not waited for without bound: this thread holds its own slot, and two threads
+        // moving graphs in opposite directions must not wait for each other forever -- normally the other slot is busy with ANOTHER
+        // graph's call and frees up within that call's time
+        const int os = it->second->slot;
+        std::unique_lock<std::mutex> old_slot(g_slot_mu[os], std::try_to_lock);
+        for (const auto t0 = std::chrono::steady_clock::now(); !old_slot.owns_lock(); (void)old_slot.try_lock()) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
+                fail(ERR_UNSUPPORTED, "graph %p was last solved on device slot %d, which other threads kept busy for 10 s: one graph is driven from one slot at a "
+                     "time (the call on slot %d did nothing)", (const void *)g, os, t_slot);
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        it = g_packs.find(g);
+        if (it != g_packs.end() && it->second->slot != t_slot) { it->second->release(); g_packs.erase(it); it = g_packs.end(); }
+    }
     if (it == g_packs.end()) {
         auto p = std::make_unique<GraphPack>();
         p->slot = t_slot;
-        HIPCHECK(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+        p->stream = take_stream(t_slot);
         it = g_packs.emplace(g, std::move(p)).first;
     }
     return *it->second;
@@ -204,7 +245,7 @@ static void upload_factors(GraphPack &gp) {
     if (F > gp.F_cap) {           // reallocation loses the old content: re-upload everything
         gp.F_cap = std::max(F, gp.F_cap + gp.F_cap / 2 + 64);
         gp.d_fa.need(gp.F_cap); gp.d_fb.need(gp.F_cap); gp.d_z.need((size_t)3 * gp.F_cap); gp.d_W.need((size_t)9 * gp.F_cap);
-        gp.d_chi2f.need(gp.F_cap);
+        gp.d_chi2f.need((size_t)gp.F_cap + REDUCE_PARTS);       // per-factor terms + the partial sums of device_chi2
         gp.F_on_device = 0;
     }
     const int f0 = gp.F_on_device;

@@ -305,6 +305,12 @@ void aprilsam_amd_clear_error(void);
  *   "speculate_factors" 1 (default): a warm april_graph_cholesky call on an unchanged graph launches the step on the packed factor
  *                       copies first and reads every factor object (z / W edited in place?) while the GPU works; an edit voids that
  *                       run and the call starts over (stats.reserved1 = 1).  0 = read the factor objects before launching
+ *   "warm_up"           1 (default): the first april_graph_cholesky_param_init of a process initialises what the HIP runtime sets up
+ *                       lazily -- two streams (8-20 ms each: a graph owns one), the copy engines' queues (7 ms per direction), the code object (2 ms), the graph
+ *                       machinery (8 ms) -- so that those milliseconds do not land inside the first solver calls (or, for the first
+ *                       device-to-host copy, inside an incremental step a thousand steps into a run).  Without a device it does
+ *                       nothing.  0 (set APRILSAM_AMD_WARM_UP=0 in the environment: it is read before the first param exists) =
+ *                       everything stays lazy.  Streams are recycled per device slot either way (a released graph parks its stream)
  *   "inc_fast"          0 = every incremental step re-plans (default 1: frozen base plan + dirty root paths)
  *   "inc_multi"         0 = incremental steps launch their fronts / back substitution level by level (default 1: one multi-level
  *                       launch per direction, fronts synchronised by dependency flags)

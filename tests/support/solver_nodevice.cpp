@@ -58,6 +58,7 @@ int api_set_device(int) { return -1; }
 int api_param_set_device(const april_graph_cholesky_param_t *, int) { return -1; }
 int api_param_get_device(const april_graph_cholesky_param_t *) { return -1; }
 void unbind_param(const april_graph_cholesky_param_t *) {}
+void warm_up() noexcept {}
 int api_set_option(const char *name, double v) {
     if (name && !strcmp(name, "leaf_nodes")) { g_opt.leaf_nodes = (int)v; return 0; }
     if (name && !strcmp(name, "pin_last")) { g_opt.pin_last = (int)v; return 0; }

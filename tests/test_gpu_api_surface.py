@@ -434,6 +434,43 @@ def test_factor_edited_in_place_on_a_growing_graph_matches_the_live_reference(li
         _same(a, b, what=f"step {k}")
 
 
+# ---- the runtime's lazy initialisations: at april_graph_cholesky_param_init, not inside the first solver calls ----------------
+def _first_call(env_extra):
+    env = dict(os.environ); env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_call.py"), "--chi2"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ms = {}; chi2 = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("first april_graph_cholesky (1 pose):"): ms["tiny"] = float(ln.split(":")[1].split()[0])
+        if ln.startswith("first call on M3500"): ms["m3500"] = float(ln.split(":")[1].split()[0])
+        if ln.startswith("chi2 after two M3500 calls:"): chi2 = ln.split(":")[1].strip()
+    assert "tiny" in ms and "m3500" in ms and chi2 is not None, r.stdout
+    return ms, chi2
+
+
+def test_warm_up_moves_the_lazy_initialisations_out_of_the_first_solver_calls(built):
+    """option warm_up (solver.hip.cpp: warm_up): with it the first call of a fresh process is a solver call, not 20 ms of stream /
+    copy-engine / code-object set-up; without it (APRILSAM_AMD_WARM_UP=0) everything stays lazy; the results are the same bits"""
+    warm, chi_w = _first_call({})
+    lazy, chi_l = _first_call({"APRILSAM_AMD_WARM_UP": "0"})
+    assert chi_w == chi_l, (chi_w, chi_l)
+    assert warm["tiny"] < 0.5 * lazy["tiny"], (warm, lazy)          # measured 0.5 against 24 ms
+    assert warm["tiny"] < 8.0, warm
+
+
+def test_a_graph_per_solve_recycles_its_stream_and_gives_the_same_bits(lib):
+    """solver_pack.inc.h: take_stream / park_stream -- a released graph parks its stream, the next graph of the slot takes it"""
+    arr = datasets.m3500_batch()
+    ref = None
+    for k in range(6):
+        g = lib.new_graph(); g.build_from_arrays(*arr); p = lib.new_param()
+        g.cholesky(p); g.cholesky(p)
+        st = g.states().copy(); c = g.chi2()
+        if ref is None: ref = (st, c)
+        else: assert np.array_equal(st, ref[0]) and c == ref[1], k
+        p.destroy(); g.destroy()
+
+
 # ---- bench.py --gpus 2, before the 8-GPU node meets it ---------------------------------------------------------------------
 def test_bench_two_ranks_on_one_gpu_prints_one_valid_line(built):
     """the driver's multi-GPU command line, with the two ranks sharing cuda:0 and gloo instead of RCCL (two ranks cannot share

@@ -20,3 +20,5 @@ ta = time.perf_counter(); g.cholesky(p); tb = time.perf_counter(); print(f"secon
 g2 = lib.new_graph(); g2.build_from_arrays(*datasets.m3500_batch()); p2 = lib.new_param()
 ta = time.perf_counter(); g2.cholesky(p2); tb = time.perf_counter(); print(f"first call on M3500 (new param, warm process): {1e3*(tb-ta):.2f} ms")
 ta = time.perf_counter(); g2.cholesky(p2); tb = time.perf_counter(); print(f"second: {1e3*(tb-ta):.3f} ms")
+if "--chi2" in sys.argv:
+    print(f"chi2 after two M3500 calls: {g2.chi2()!r}")
