@@ -3,7 +3,7 @@
 # usage: bash tools/soak_matrix.sh seconds "name copies VAR=value ..." ...
 T=${1:-300}; shift
 mkdir -p gpurun_out/soak; rm -f gpurun_out/soak/*.log
-SEED=100
+SEED=${SOAK_SEED0:-100}          # (SOAK_SEED0=1000: another set of random orders)
 for spec in "$@"; do
   set -- $spec; name=$1; copies=$2; shift 2
   script=tools/soak_batch.py                 # SOAK_SCRIPT=tools/soak_inc.py in a spec: the incremental demo's soak instead of the batch path's
