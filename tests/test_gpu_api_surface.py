@@ -471,6 +471,22 @@ def test_a_graph_per_solve_recycles_its_stream_and_gives_the_same_bits(lib):
         p.destroy(); g.destroy()
 
 
+def test_chi2_of_a_large_graph_sums_in_two_stages_reproducibly(lib):
+    """april_graph_chi2 above 65 536 factors (kernels.hip.h: k_reduce_parts + k_reduce): the 100 k lattice's 397 531 terms -- the same bits on
+    every call, the unmodified reference's value (bench.LATTICE100K_CHI2, golden of oracle/_ref) to rounding; below the limit the one-stage sum"""
+    import bench
+    g = lib.new_graph(); nfac = lib.dll.aprilsam_amd_make_lattice(g.ptr, 316)
+    assert nfac == 397531
+    c = [g.chi2() for _ in range(4)]
+    assert c[0] == c[1] == c[2] == c[3]
+    assert abs(c[0] - bench.LATTICE100K_CHI2[0]) / bench.LATTICE100K_CHI2[0] < 1e-13
+    g.destroy()
+    g = lib.new_graph(); assert lib.dll.aprilsam_amd_make_lattice(g.ptr, 100) < 65536
+    c = [g.chi2() for _ in range(3)]
+    assert c[0] == c[1] == c[2] and c[0] > 0
+    g.destroy()
+
+
 # ---- bench.py --gpus 2, before the 8-GPU node meets it ---------------------------------------------------------------------
 def test_bench_two_ranks_on_one_gpu_prints_one_valid_line(built):
     """the driver's multi-GPU command line, with the two ranks sharing cuda:0 and gloo instead of RCCL (two ranks cannot share
